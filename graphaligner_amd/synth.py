@@ -1,0 +1,306 @@
+"""Deterministic synthetic graphs and reads (no real genomes are available offline).
+
+Scales and parameters follow SURVEY.md section 8(d): seeded random genomes, variation bubbles
+at 1000GP-like density, node length capped (the reference never splits nodes and abandons
+the bit-vector method once a band holds >= 200000 bp, GraphAlignerCommon.h:10), reads drawn
+from haplotype walks with the error model of the reference's SimulateReads.cpp:12-41 under a
+fixed seed (the reference's own simulator is time-seeded, SimulateReads.cpp:131, so it cannot
+define fixtures).
+
+Graphs are *bidirected* (vg style): nodes (id, sequence), edges (from, from_start, to,
+to_end).  All edges produced here are end->start (from_start = to_end = False).
+"""
+import numpy as np
+
+_ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[a] = b
+
+
+def revcomp_bytes(a):
+    return _COMP[a[::-1]]
+
+
+def random_genome(n, seed):
+    rng = np.random.default_rng(seed)
+    return _ALPHA[rng.integers(0, 4, size=n, dtype=np.uint8)]
+
+
+class SynthGraph:
+    """a variation graph over one backbone genome; node ids are 1.. in topological order"""
+
+    def __init__(self, genome, node_len=64, snp_every=0, indel_every=0, sv_every=0, seed=0, max_indel=20):
+        self.genome = genome
+        self.node_len = node_len
+        rng = np.random.default_rng(seed)
+        n = len(genome)
+        # ---- choose variant sites (sorted, at least 2 backbone bases apart) -----------------
+        variants = []   # (pos, kind, ref_len, alt bytes)
+        pos = 0
+        rates = [(snp_every, "snp"), (indel_every, "indel"), (sv_every, "sv")]
+        total_rate = sum(1.0 / r for r, _ in rates if r)
+        if total_rate > 0:
+            kinds = [k for r, k in rates if r]
+            probs = np.array([1.0 / r for r, _ in rates if r]) / total_rate
+            pos = 1 + int(rng.geometric(total_rate))
+            while pos < n - 600:
+                kind = kinds[int(rng.choice(len(kinds), p=probs))]
+                if kind == "snp":
+                    ref = genome[pos]
+                    alt = _ALPHA[(int(np.searchsorted(_ALPHA, ref)) + 1 + int(rng.integers(0, 3))) % 4]
+                    variants.append((pos, "snp", 1, np.array([alt], dtype=np.uint8)))
+                    pos += 1
+                else:
+                    ln = int(rng.integers(1, max_indel + 1)) if kind == "indel" else int(rng.integers(50, 501))
+                    if rng.random() < 0.5:
+                        variants.append((pos, "del", ln, np.zeros(0, dtype=np.uint8)))
+                        pos += ln
+                    else:
+                        variants.append((pos, "ins", 0, _ALPHA[rng.integers(0, 4, size=ln, dtype=np.uint8)]))
+                pos += 2 + int(rng.geometric(total_rate))
+        self.variants = variants
+        # ---- build nodes / edges -------------------------------------------------------------
+        self.nodes = []          # (id, str)
+        self.edges = []          # (from, False, to, False)
+        self.node_at = np.zeros(n, dtype=np.int32)     # backbone position -> node id (ref allele path)
+        self.node_off = np.zeros(n, dtype=np.int32)    # offset inside that node
+        self._next_id = 1
+        tails = []
+
+        def add_chain(seq_bytes, tails_in, backbone_start=None):
+            """chop into <= node_len nodes, link tails_in -> first, return id of last"""
+            last = None
+            for k in range(0, len(seq_bytes), node_len):
+                piece = seq_bytes[k:k + node_len]
+                nid = self._next_id
+                self._next_id += 1
+                self.nodes.append((nid, piece.tobytes().decode()))
+                if last is None:
+                    for t in tails_in:
+                        self.edges.append((t, False, nid, False))
+                else:
+                    self.edges.append((last, False, nid, False))
+                if backbone_start is not None:
+                    a = backbone_start + k
+                    self.node_at[a:a + len(piece)] = nid
+                    self.node_off[a:a + len(piece)] = np.arange(len(piece), dtype=np.int32)
+                last = nid
+            return last
+
+        cur = 0
+        for (p, kind, ref_len, alt) in variants:
+            if p > cur:
+                tails = [add_chain(genome[cur:p], tails, cur)]
+            if kind == "snp":
+                r = add_chain(genome[p:p + 1], tails, p)
+                a = add_chain(alt, tails)
+                tails = [r, a]
+                cur = p + 1
+            elif kind == "del":
+                d = add_chain(genome[p:p + ref_len], tails, p)
+                tails = tails + [d]
+                cur = p + ref_len
+            else:
+                i = add_chain(alt, tails)
+                tails = tails + [i]
+                cur = p
+        if cur < n:
+            add_chain(genome[cur:n], tails, cur)
+        self.var_pos = np.array([v[0] for v in variants], dtype=np.int64)
+
+    # ---- export -------------------------------------------------------------------------------
+    def gfa(self, overlap=0):
+        lines = ["H\tVN:Z:1.0"]
+        for nid, seq in self.nodes:
+            lines.append("S\t%d\t%s" % (nid, seq))
+        for f, fs, t, te in self.edges:
+            lines.append("L\t%d\t%s\t%d\t%s\t%dM" % (f, "-" if fs else "+", t, "-" if te else "+", overlap))
+        return "\n".join(lines) + "\n"
+
+    # ---- haplotypes & reads -----------------------------------------------------------------------
+    def haplotype_window(self, start, length, rng):
+        """bytes of one random haplotype starting at backbone position `start` (which must be a
+        backbone/ref position), at least `length` long when the genome allows"""
+        out = []
+        have = 0
+        cur = start
+        lo = int(np.searchsorted(self.var_pos, start, side="left"))
+        k = lo
+        n = len(self.genome)
+        while have < length and cur < n:
+            nxt = self.variants[k][0] if k < len(self.variants) else n
+            if nxt > cur:
+                take = min(nxt - cur, length - have)
+                out.append(self.genome[cur:cur + take])
+                have += take
+                cur += take
+                if have >= length:
+                    break
+            if k >= len(self.variants):
+                continue
+            p, kind, ref_len, alt = self.variants[k]
+            k += 1
+            use_alt = rng.random() < 0.5
+            if kind == "snp":
+                out.append(alt if use_alt else self.genome[p:p + 1])
+                have += 1
+                cur = p + 1
+            elif kind == "del":
+                if not use_alt:
+                    out.append(self.genome[p:p + ref_len])
+                    have += ref_len
+                cur = p + ref_len
+            else:
+                if use_alt:
+                    out.append(alt)
+                    have += len(alt)
+                cur = p
+        hap = np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+        return hap[:length]
+
+    def _backbone_start(self, p):
+        """move p right until it is a plain backbone position (not inside a variant site)"""
+        while True:
+            k = int(np.searchsorted(self.var_pos, p, side="right")) - 1
+            if k >= 0:
+                vp, kind, ref_len, _ = self.variants[k]
+                span = 1 if kind == "snp" else ref_len
+                if vp <= p < vp + span:
+                    p = vp + span
+                    continue
+            return p
+
+
+def add_errors(seq, sub, ins, dele, rng):
+    """SimulateReads.cpp:12-41: per base: drop w.p. dele; else substitute w.p. sub by a uniform
+    base (may equal the original); then w.p. ins/10 insert uniform(0..19) uniform bases."""
+    n = len(seq)
+    keep = rng.random(n) >= dele
+    subm = rng.random(n) < sub
+    s = seq.copy()
+    ns = int(subm.sum())
+    if ns:
+        s[subm] = _ALPHA[rng.integers(0, 4, size=ns, dtype=np.uint8)]
+    insm = rng.random(n) < ins / 10.0
+    if not insm.any():
+        return s[keep]
+    pieces = []
+    last = 0
+    for i in np.nonzero(insm)[0]:
+        seg_keep = keep[last:i + 1]
+        pieces.append(s[last:i + 1][seg_keep])
+        ln = int(rng.integers(0, 20))
+        if ln:
+            pieces.append(_ALPHA[rng.integers(0, 4, size=ln, dtype=np.uint8)])
+        last = i + 1
+    pieces.append(s[last:][keep[last:]])
+    return np.concatenate(pieces)
+
+
+def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1, both_strands=True, mid_seed=False):
+    """returns (reads, seeds): reads are str, seeds are (bigraph node id, read position, reverse).
+    The seed names the node holding the read's first base (position 0) or, with mid_seed, the
+    node holding the base at the middle of the read (exercises the backward extension)."""
+    rng = np.random.default_rng(seed)
+    g = graph
+    n = len(g.genome)
+    reads, seeds = [], []
+    while len(reads) < n_reads:
+        start = g._backbone_start(int(rng.integers(0, max(1, n - length - 1200))))
+        hap = g.haplotype_window(start, length, rng)
+        if len(hap) < length:
+            continue
+        reverse = both_strands and rng.random() < 0.5
+        # the haplotype ends somewhere; for seeding we need a backbone anchor at the read's
+        # first base.  Forward reads: `start`.  Reverse reads: the last base of the window must
+        # be a backbone base, so rebuild the window to end at a backbone position.
+        if not reverse:
+            if mid_seed:
+                half = length // 2
+                # first half = haplotype from start up to a backbone anchor, second half from it
+                anchor = g._backbone_start(start + half)
+                first = _hap_until(g, start, anchor, rng)
+                second = g.haplotype_window(anchor, length - half, rng)
+                a = add_errors(first, sub, ins, dele, rng)
+                b = add_errors(second, sub, ins, dele, rng)
+                if len(a) < 200 or len(b) < 200:
+                    continue
+                reads.append(np.concatenate([a, b]).tobytes().decode())
+                seeds.append((int(g.node_at[anchor]), len(a), False))
+            else:
+                r = add_errors(hap, sub, ins, dele, rng)
+                if len(r) < 200:
+                    continue
+                reads.append(r.tobytes().decode())
+                seeds.append((int(g.node_at[start]), 0, False))
+        else:
+            # walk forward from `start`, stop at a backbone anchor near start+length
+            anchor = g._backbone_start(start + length)
+            if anchor >= n - 1:
+                continue
+            body = _hap_until(g, start, anchor + 1, rng)     # includes the anchor base
+            if len(body) < 200:
+                continue
+            rc = revcomp_bytes(body)
+            if mid_seed:
+                mid_anchor = g._backbone_start(start + length // 2)
+                left = _hap_until(g, start, mid_anchor + 1, rng)
+                right = _hap_until(g, mid_anchor + 1, anchor + 1, rng)
+                a = add_errors(revcomp_bytes(right), sub, ins, dele, rng)
+                b = add_errors(revcomp_bytes(left), sub, ins, dele, rng)
+                if len(a) < 200 or len(b) < 200:
+                    continue
+                reads.append(np.concatenate([a, b]).tobytes().decode())
+                seeds.append((int(g.node_at[mid_anchor]), len(a), True))
+            else:
+                r = add_errors(rc, sub, ins, dele, rng)
+                if len(r) < 200:
+                    continue
+                reads.append(r.tobytes().decode())
+                seeds.append((int(g.node_at[anchor]), 0, True))
+    return reads, seeds
+
+
+def _hap_until(g, start, stop, rng):
+    """random haplotype covering backbone interval [start, stop) (both backbone positions)"""
+    out = []
+    cur = start
+    k = int(np.searchsorted(g.var_pos, start, side="left"))
+    while cur < stop:
+        nxt = g.variants[k][0] if k < len(g.variants) else stop
+        nxt = min(nxt, stop)
+        if nxt > cur:
+            out.append(g.genome[cur:nxt])
+            cur = nxt
+            if cur >= stop:
+                break
+        if k >= len(g.variants):
+            break
+        p, kind, ref_len, alt = g.variants[k]
+        if p >= stop:
+            break
+        k += 1
+        use_alt = rng.random() < 0.5
+        if kind == "snp":
+            out.append(alt if use_alt else g.genome[p:p + 1])
+            cur = p + 1
+        elif kind == "del":
+            if not use_alt:
+                out.append(g.genome[p:p + ref_len])
+            cur = p + ref_len
+        else:
+            if use_alt:
+                out.append(alt)
+            cur = p
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+
+
+def linear_graph(n, node_len=64, seed=42):
+    """E. coli-like single chain of node_len-bp nodes"""
+    return SynthGraph(random_genome(n, seed), node_len=node_len)
+
+
+def bubble_graph(n, node_len=64, seed=44, snp_every=100, indel_every=1000, sv_every=50000):
+    """yeast-like pangenome: SNP / short-indel / SV bubbles"""
+    return SynthGraph(random_genome(n, seed), node_len=node_len, snp_every=snp_every, indel_every=indel_every, sv_every=sv_every, seed=seed + 1)

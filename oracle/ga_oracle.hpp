@@ -1,0 +1,151 @@
+// ga_oracle.hpp -- CPU restatement of GraphAligner's seeded, banded, bit-parallel
+// sequence-to-graph alignment (the path behind AlignOneWay, GraphAlignerWrapper.h:53-54).
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may build, link or call anything under oracle/.  The product
+// (graphaligner_amd/) never includes or links this file.
+//
+// PARITY STATUS: *parity unpinned* end-to-end.  The reference ships no expected outputs
+//  and its hot path (GraphAligner.h) cannot be compiled in this image without
+// stand-ins for protobuf-generated vg.pb.h and for boost headers, so it is treated as
+// unbuildable.  What IS pinned: the pieces that compile from the reference's own
+// self-contained files (WordSlice.h merge / getValue, NodeSlice.h freeze / thaw,
+// AlignmentCorrectnessEstimation.cpp) are built by oracle/Makefile into oracle/_ref/ and the
+// corresponding functions here are checked against them (tests/test_oracle_refparts.py).
+//
+// Every function cites the reference file:line it follows.  The code is a restatement
+// written for this repository, not a copy: containers, control structure and naming are
+// its own, but wherever the reference's *iteration order* influences the result
+// (std::unordered_map of a frozen slice, std::priority_queue tie order, Tarjan emission
+// order) the same libstdc++ containers are used in the same sequence so the order is
+// identical by construction.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <limits>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+namespace gao {
+
+using u64 = uint64_t;
+
+// ---- status codes reported instead of C++ exceptions ------------------------------------
+enum Status : int {
+	OK = 0,
+	ASSERTION = 1,       // the reference's always-on assert() would have thrown (ThreadReadAssertion.cpp:19-25)
+	UNSUPPORTED = 2,     // band >= 200000 cells: sparse method / BacktraceOverride not restated (GraphAligner.h:2148-2329,167-354)
+	BAD_SEED = 3,        // nodeLookup.at() would throw std::out_of_range (GraphAligner.h:423)
+};
+
+struct Failure { Status status; std::string what; };
+
+// ---- graph model (AlignmentGraph.h:13-60, AlignmentGraph.cpp:12-154,199-260) --------------
+class Graph {
+public:
+	Graph();
+	void addNode(int digraphId, const std::string& seq, bool reverseNode);   // AlignmentGraph.cpp:47-89
+	void addEdge(int fromDigraphId, int toDigraphId);                       // AlignmentGraph.cpp:91-106
+	void finalize();                                                        // AlignmentGraph.cpp:108-154
+	// bidirected helpers (BigraphToDigraph.cpp:27-56, 58-104)
+	void addBigraphNode(int id, const std::string& seq);
+	void addBigraphEdge(int from, bool fromStart, int to, bool toEnd);
+
+	size_t nodeCount() const { return start.size(); }
+	size_t bp() const { return bases.size(); }
+	size_t nodeBegin(size_t n) const { return start[n]; }
+	size_t nodeEnd(size_t n) const { return n + 1 == start.size() ? bases.size() : start[n + 1]; }
+	size_t nodeLen(size_t n) const { return nodeEnd(n) - nodeBegin(n); }
+	size_t nodeOf(size_t column) const;                                     // AlignmentGraph.cpp:226-234
+	char base(size_t column) const;                                         // AlignmentGraph.cpp:251-260
+	size_t reverseNode(size_t n) const;                                     // AlignmentGraph.cpp:199-214
+	size_t reverseColumn(size_t column) const;                              // AlignmentGraph.cpp:216-224
+
+	int dbgOverlap = 0;
+	std::vector<size_t> start;
+	std::unordered_map<int, size_t> lookup;
+	std::vector<int> ids;
+	std::vector<std::vector<size_t>> in, out;
+	std::vector<bool> rev;
+	std::string bases;            // 'A','C','G','T'; '-' for the two dummy columns
+	size_t dummyFirst = 0, dummyLast = 0;
+	bool finalized = false;
+};
+
+// ---- WordSlice (WordSlice.h:172-200) -------------------------------------------------------
+struct Column {
+	u64 vp = 0, vn = 0;
+	int end = 0;              // scoreEnd         (row j+63)
+	int before = 0;           // scoreBeforeStart (row j-1)
+	int rows = 0;             // confirmedRows.rows
+	bool partial = false;     // confirmedRows.partial
+	bool beforeExists = false;
+	bool endExists = true;
+};
+
+int columnValue(const Column& c, int row);                                  // WordSlice.h:223-229
+Column mergeColumns(Column a, Column b);                                    // WordSlice.h:202-206, 361-421 (+423-510)
+Column stepColumn(u64 eq, Column left, bool upInBand, bool upLeftInBand, bool diagInBand,
+                  bool prevRowEq, const Column& above, int lastRowMin);     // GraphAligner.h:1349-1427
+bool charMatch(char readChar, char graphChar);                              // GraphAligner.h:2039-2110 (throws Failure)
+std::string reverseComplement(const std::string& s);                        // CommonUtils.cpp:60-136 (throws Failure)
+
+// ---- HMM (AlignmentCorrectnessEstimation.cpp:6-89) ------------------------------------------
+struct Hmm {
+	double correct, wrong;
+	bool correctFromCorrect = false, falseFromCorrect = false;
+	Hmm();
+	bool currentlyCorrect() const { return correct > wrong; }
+	Hmm next(int mismatches, int rowSize) const;
+};
+
+// ---- results --------------------------------------------------------------------------------
+struct Mapping {               // vg::Mapping with its single vg::Edit (GraphAligner.h:782-847)
+	int64_t nodeId = 0;        // DIGRAPH id (2*id or 2*id+1); the driver halves it (Aligner.cpp:83-91)
+	bool isReverse = false;
+	int64_t offset = 0;
+	int rank = 0;
+	int64_t fromLength = 0, toLength = 0;
+	std::string editSeq;
+};
+enum TraceType { MATCH = 1, MISMATCH = 2, INSERTION = 3, DELETION = 4, FORWARDBACKWARDSPLIT = 5 };
+struct TraceItem {             // GraphAlignerWrapper.h:22-31
+	int nodeID; size_t offset; bool reverse; size_t readpos; int type; char graphChar, readChar;
+};
+struct AlignResult {           // GraphAlignerWrapper.h:10-51
+	Status status = OK;
+	std::string message;
+	bool failed = true;
+	int32_t score = std::numeric_limits<int32_t>::max();
+	size_t alignmentStart = 0, alignmentEnd = 0, queryPosition = 0;
+	std::vector<Mapping> mappings;
+	std::vector<TraceItem> trace;
+	// raw traces (column,row) of the chosen seed, for kernel-level parity checks
+	std::vector<std::pair<size_t, size_t>> fwTrace, bwTrace;
+	int32_t fwScore = 0, bwScore = 0;
+	size_t columnsFirstPass = 0;   // sum of DPSlice::numCells over first-pass slices (GraphAligner.h:2637)
+	size_t slicesFirstPass = 0;
+};
+
+// one first-pass slice, recorded for kernel-level golden vectors
+struct SliceRecord {
+	int direction;             // 0 forward, 1 backward
+	size_t j; int bandwidth;
+	std::vector<size_t> nodes; // processing-independent band order (DPSlice::nodes)
+	std::vector<Column> columns;   // concatenated in `nodes` order
+	int minScore; std::vector<size_t> minIndex;
+};
+
+typedef std::tuple<int, size_t, bool> Seed;   // (bigraph node id, read position, reverse)
+
+// AlignOneWay, seeded (GraphAlignerWrapper.cpp:14-19 -> GraphAligner.h:408-491)
+AlignResult alignOneWay(const Graph& g, const std::string& seqId, const std::string& sequence,
+                        int initialBandwidth, int rampBandwidth, const std::vector<Seed>& seeds,
+                        std::vector<SliceRecord>* record = nullptr);
+
+// iteration order of a frozen slice whose live form received `nodes` in this order (test hook)
+std::vector<size_t> frozenIterationOrder(const std::vector<size_t>& nodes, size_t graphNodes);
+
+}  // namespace gao
