@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned Gbp/s of the seed-and-extend hot path on MI355X.
+
+One "step" = one pass of the extension kernel over one batch of synthetic reads that is
+already resident in HBM (reads coded and uploaded, graph uploaded, before the timed region).
+
+Workload at N=1 (BASELINE.json configs[1], restated synthetically as SURVEY.md 8(d) C2):
+  E. coli-scale linear graph: 4,641,652 bp uniform ACGT (seed 42) as one chain of 64-bp nodes,
+  50,000 reads x 10,000 bp drawn from it, SimulateReads-style errors s=i=d=0.04 (seed 43),
+  both strands, one seed hit per read at read position 0, bandwidth 35, no ramp.
+With --gpus N every rank runs its own 50,000-read shard (different read seed) against a graph
+replicated in its GPU's HBM -- weak scaling, no collective on the data path.
+
+Prints ONE JSON line (rank 0): metric/value per the driver contract plus `roofline`
+(algorithmic 28 B per column update / live HIP-event kernel time vs 8 TB/s HBM) and
+`cpu_baseline` (the CPU oracle, multi-threaded, on a bounded sample of the same reads).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_COLUMN_UPDATE = 28.0      # 0.25 base + 4 prev end + 4 end out + 20 VP/VN/score
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=50000)
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--genome", type=int, default=4641652)
+    ap.add_argument("--node-len", type=int, default=64)
+    ap.add_argument("--bandwidth", type=int, default=35)
+    ap.add_argument("--graph", choices=["linear", "bubbles"], default="linear")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--check", type=int, default=4, help="reads compared with the oracle after the run")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the aligner has no CPU path")
+    torch.cuda.set_device(local)
+
+    import __graft_entry__ as entry
+    entry.build_product()
+    from graphaligner_amd import binding, synth
+
+    t0 = time.time()
+    if args.graph == "linear":
+        g = synth.linear_graph(args.genome, node_len=args.node_len, seed=42)
+    else:
+        g = synth.bubble_graph(args.genome, node_len=args.node_len, seed=44)
+    reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=0.04, ins=0.04, dele=0.04, seed=43 + 1000 * rank)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    graph = binding.Graph(gfa=g.gfa(), device=local)
+    batch = graph.prepare(reads, seeds, args.bandwidth, 0)
+    t_prep = time.time() - t0
+    total_bp = batch.total_bp
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+        kernel_ms.append(batch.stats()["kernel_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # what was aligned (reads returned with failed = 0), from one collect after the timed region
+    t0 = time.time()
+    results = batch.collect()
+    t_collect = time.time() - t0
+    st = batch.stats()
+    aligned_bp = sum(len(r) for r, res in zip(reads, results) if not res["failed"])
+    n_failed = sum(1 for res in results if res["failed"])
+    if world > 1:
+        t = torch.tensor([float(aligned_bp)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        aligned_total = float(t.item())
+    else:
+        aligned_total = float(aligned_bp)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = aligned_total / (elapsed / args.steps) / 1e9
+    k_ms = float(np.mean(kernel_ms))
+    achieved = BYTES_PER_COLUMN_UPDATE * st["column_updates"] / (k_ms * 1e-3) / 1e9
+    out = {
+        "metric": "aligned Gbp/sec (whole node), 10kb ONT reads vs chr-scale GFA",
+        "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "E. coli-scale linear GFA (%d bp, %d-bp nodes, seed 42) + %d x %d bp simulated ONT-error reads (s=i=d=0.04, seed 43), band=%d, 1 seed/read at pos 0"
+                               % (args.genome, args.node_len, args.reads, args.read_len, args.bandwidth) if args.graph == "linear" else
+                               "pangenome-like bubble graph (%d bp, %d-bp nodes, seed 44) + %d x %d bp reads, band=%d" % (args.genome, args.node_len, args.reads, args.read_len, args.bandwidth),
+                   "reads_per_gpu": args.reads, "read_len": args.read_len, "bandwidth": args.bandwidth, "graph_bp_both_strands": int(graph.bp),
+                   "parallelism": "reads sharded, graph replicated, no collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": None, "kernel": "ga_extend_kernel<64>", "kernel_ms": round(k_ms, 3),
+                     "column_updates_per_launch": int(st["column_updates"]), "bytes_per_column_update": BYTES_PER_COLUMN_UPDATE},
+        "detail": {"reads_failed": n_failed, "jobs": int(st["n_jobs"]), "jobs_retried_wide": int(st["jobs_retried"]), "slots": int(st["slots"]),
+                   "scratch_GB": round(st["scratch_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "prepare_s": round(t_prep, 1), "collect_s": round(t_collect, 1),
+                   "kernel_only_Gbp_s": round(aligned_bp / (k_ms * 1e-3) / 1e9, 4)},
+    }
+
+    # ---- CPU baseline: the oracle (a port of the reference algorithm), all host cores, bounded sample ----
+    if args.cpu_sample > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding as ob
+        cores = os.cpu_count() or 1
+        n = min(args.cpu_sample, len(reads))
+        og = ob.OracleGraph(g.nodes, g.edges)
+        b = og.bench(reads[:n], seeds[:n], args.bandwidth, 0, cores)
+        out["cpu_baseline"] = {"value": round(b["aligned_bp"] / b["seconds"] / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
+                               "sample": "first %d reads of the same batch, %d threads popping reads from a shared queue (Aligner.cpp:285-298), %.1f s" % (n, cores, b["seconds"])}
+        # spot check: the GPU results for a few reads against the oracle
+        import parity_common as pc
+        for i in range(min(args.check, n)):
+            pc.compare_read(dict(results[i], trace=np.zeros((0, 7), dtype=np.int64)), dict(og.align(reads[i], [seeds[i]], args.bandwidth), trace=np.zeros((0, 7), dtype=np.int64)), "bench read %d" % i)
+        out["detail"]["oracle_spot_check_reads"] = min(args.check, n)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

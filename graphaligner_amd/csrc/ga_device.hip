@@ -1,0 +1,293 @@
+// ga_device.hip -- gfx950 back end: keeps the flattened graph resident in HBM and runs the
+// extension program (ga_kernel.h) as a persistent launch: one 64-lane workgroup (= one
+// wavefront) per slot, each slot pulling read directions from a device-side queue and owning a
+// private region of HBM for its slices' VP/VN words.  Reads are independent, so there is no
+// inter-workgroup communication besides the queue counter and the trace-pool bump counter.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/graphaligner_amd.h"
+#include "ga_backend.h"
+#include "ga_kernel.h"
+
+namespace {
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "graphaligner_amd: %s failed: %s\n", #call, hipGetErrorString(e_)); return GA_E_DEVICE; } } while (0)
+
+struct SlotLayout
+{
+	uint64_t endPrev, endCur, sliceOff, arena, trace, flags, bytes;
+};
+__host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxSlices, uint64_t arenaWords, uint32_t traceCap)
+{
+	auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
+	SlotLayout l;
+	uint64_t at = 0;
+	l.endPrev = at; at = up(at + 4ull * capCols);
+	l.endCur = at; at = up(at + 4ull * capCols);
+	l.sliceOff = at; at = up(at + 4ull * (maxSlices + 1));
+	l.arena = at; at = up(at + 4ull * arenaWords);
+	l.trace = at; at = up(at + 12ull * traceCap);
+	l.flags = at; at = up(at + maxSlices + 1);
+	l.bytes = at;
+	return l;
+}
+
+template <int MAXN>
+__global__ void __launch_bounds__(64) ga_extend_kernel(GaLaunch L)
+{
+	__shared__ gak::WaveState<MAXN> ws;
+	const SlotLayout lay = slotLayout(L.cap_cols, L.max_slices, L.arena_words, L.trace_cap);
+	uint8_t* base = L.scratch + (uint64_t)blockIdx.x * L.slot_bytes;
+	gak::Slot slot;
+	slot.end_prev = (uint32_t*)(base + lay.endPrev);
+	slot.end_cur = (uint32_t*)(base + lay.endCur);
+	slot.slice_off = (uint32_t*)(base + lay.sliceOff);
+	slot.arena = (uint32_t*)(base + lay.arena);
+	slot.trace = (GaTraceStep*)(base + lay.trace);
+	slot.slice_flags = base + lay.flags;
+	while (true)
+	{
+		uint32_t k = gaw::wave_atomic_add(L.next_job, 1u);
+		if (k >= L.n_jobs) break;                      // every wave reaches this exit once the queue is drained
+		uint32_t job = L.job_list ? L.job_list[k] : k;
+		gak::run_job<MAXN>(L, ws, slot, job);
+		__syncthreads();
+	}
+}
+
+struct DevGraph : GaBackendGraph
+{
+	int device = 0;
+	GaDevGraph g;
+	GaHmmTables* hmm = nullptr;
+	std::vector<void*> allocs;
+	int cus = 0;
+	~DevGraph() override { hipSetDevice(device); for (void* p : allocs) hipFree(p); }
+	template <typename T> int put(const std::vector<T>& v, const T** out)
+	{
+		void* p = nullptr;
+		HIP_OK(hipMalloc(&p, std::max<size_t>(v.size() * sizeof(T), 16)));
+		allocs.push_back(p);
+		HIP_OK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+		*out = (const T*)p;
+		return 0;
+	}
+};
+
+struct DevBatch : GaBackendBatch
+{
+	DevGraph* g = nullptr;
+	hipStream_t stream = nullptr;
+	hipEvent_t evStart = nullptr, evStop = nullptr;
+	std::vector<void*> allocs;
+	std::vector<GaJob> jobs;
+	GaRunConfig cfg;
+	GaLaunch L;                 // main launch
+	uint32_t slots = 0, wavesPerCu = 0;
+	std::vector<GaJobOut> outs;
+	GaRunStats st;
+	// retry pass (wide variant), built lazily
+	uint8_t* retryScratch = nullptr;
+	uint32_t* retryList = nullptr;
+	size_t retryScratchBytes = 0;
+
+	~DevBatch() override
+	{
+		hipSetDevice(g->device);
+		for (void* p : allocs) hipFree(p);
+		if (retryScratch) hipFree(retryScratch);
+		if (retryList) hipFree(retryList);
+		if (evStart) hipEventDestroy(evStart);
+		if (evStop) hipEventDestroy(evStop);
+		if (stream) hipStreamDestroy(stream);
+	}
+	template <typename T> int alloc(T** out, size_t count)
+	{
+		void* p = nullptr;
+		HIP_OK(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+		allocs.push_back(p);
+		*out = (T*)p;
+		return 0;
+	}
+
+	int init(const std::vector<uint8_t>& rows, const std::vector<GaJob>& jobsIn)
+	{
+		HIP_OK(hipSetDevice(g->device));
+		HIP_OK(hipStreamCreate(&stream));
+		HIP_OK(hipEventCreate(&evStart));
+		HIP_OK(hipEventCreate(&evStop));
+		jobs = jobsIn;
+		memset(&L, 0, sizeof(L));
+		L.graph = g->g;
+		L.hmm = g->hmm;
+		L.n_jobs = (uint32_t)jobs.size();
+		L.initial_bw = cfg.initial_bw;
+		L.ramp_bw = cfg.ramp_bw;
+		L.max_slices = std::max<uint32_t>(cfg.max_slices, 1);
+		uint8_t* dRows; GaJob* dJobs;
+		if (alloc(&dRows, rows.size())) return GA_E_DEVICE;
+		if (alloc(&dJobs, jobs.size())) return GA_E_DEVICE;
+		HIP_OK(hipMemcpyAsync(dRows, rows.data(), rows.size(), hipMemcpyHostToDevice, stream));
+		HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GaJob), hipMemcpyHostToDevice, stream));
+		L.rows = dRows;
+		L.jobs = dJobs;
+		if (alloc(&L.outs, jobs.size())) return GA_E_DEVICE;
+		if (alloc(&L.next_job, 4)) return GA_E_DEVICE;
+		if (alloc(&L.trace_top, 2)) return GA_E_DEVICE;
+		uint64_t totalRows = 0;
+		for (auto& j : jobs) totalRows += j.n_rows;
+		L.trace_pool_cap = totalRows + totalRows / 2 + 1024ull * jobs.size() + 4096;
+		if (alloc(&L.traces, L.trace_pool_cap)) return GA_E_DEVICE;
+		// slot geometry: bands of ~300-700 columns are the rule (b = 35 on variation graphs);
+		// anything wider fails with a capacity status and is rerun by the wide variant
+		L.cap_cols = 4096;
+		L.trace_cap = cfg.max_rows * 2 + 1024;
+		L.arena_words = 64 + (uint64_t)L.max_slices * (gak::kSliceHdrWords + 2 * 64 + 5 * 800);
+		SlotLayout lay = slotLayout(L.cap_cols, L.max_slices, L.arena_words, L.trace_cap);
+		L.slot_bytes = lay.bytes;
+		size_t freeB = 0, totalB = 0;
+		HIP_OK(hipMemGetInfo(&freeB, &totalB));
+		wavesPerCu = 16;
+		uint64_t want = (uint64_t)g->cus * wavesPerCu;
+		uint64_t fit = (uint64_t)(freeB * 0.8) / std::max<uint64_t>(lay.bytes, 1);
+		slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(want, fit), std::max<size_t>(jobs.size(), 1)));
+		if (alloc(&L.scratch, (size_t)slots * lay.bytes)) return GA_E_DEVICE;
+		st.slots = slots;
+		st.waves_per_cu = wavesPerCu;
+		st.scratch_bytes = (uint64_t)slots * lay.bytes;
+		HIP_OK(hipStreamSynchronize(stream));
+		return 0;
+	}
+
+	int run() override
+	{
+		HIP_OK(hipSetDevice(g->device));
+		if (jobs.empty()) { outs.clear(); return 0; }
+		HIP_OK(hipMemsetAsync(L.next_job, 0, 16, stream));
+		HIP_OK(hipMemsetAsync(L.trace_top, 0, 16, stream));
+		HIP_OK(hipEventRecord(evStart, stream));
+		hipLaunchKernelGGL(ga_extend_kernel<64>, dim3(slots), dim3(64), 0, stream, L);
+		HIP_OK(hipGetLastError());
+		HIP_OK(hipEventRecord(evStop, stream));
+		outs.resize(jobs.size());
+		HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipStreamSynchronize(stream));
+		float ms = 0;
+		HIP_OK(hipEventElapsedTime(&ms, evStart, evStop));
+		st.kernel_ms = ms;
+		// ---- capacity misses go through the wide variant (256 band nodes in LDS, larger buffers) ----
+		std::vector<uint32_t> again;
+		for (uint32_t i = 0; i < outs.size(); i++)
+		{
+			int s = outs[i].status;
+			if (s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP) again.push_back(i);
+		}
+		st.jobs_retried = again.size();
+		if (!again.empty())
+		{
+			GaLaunch R = L;
+			uint32_t maxRows = 0;
+			for (uint32_t i : again) maxRows = std::max(maxRows, jobs[i].n_rows);
+			R.cap_cols = 65536;
+			R.trace_cap = maxRows * 6 + 4096;
+			R.arena_words = 64 + (uint64_t)(maxRows / 64) * (gak::kSliceHdrWords + 2 * 256 + 5 * 8192);
+			SlotLayout lay = slotLayout(R.cap_cols, R.max_slices, R.arena_words, R.trace_cap);
+			R.slot_bytes = lay.bytes;
+			size_t freeB = 0, totalB = 0;
+			HIP_OK(hipMemGetInfo(&freeB, &totalB));
+			uint64_t fit = (uint64_t)(freeB * 0.8) / lay.bytes;
+			uint32_t rslots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * 4, fit), again.size()));
+			if ((size_t)rslots * lay.bytes > retryScratchBytes)
+			{
+				if (retryScratch) hipFree(retryScratch);
+				retryScratch = nullptr;
+				HIP_OK(hipMalloc((void**)&retryScratch, (size_t)rslots * lay.bytes));
+				retryScratchBytes = (size_t)rslots * lay.bytes;
+			}
+			if (retryList) hipFree(retryList);
+			HIP_OK(hipMalloc((void**)&retryList, again.size() * 4));
+			HIP_OK(hipMemcpyAsync(retryList, again.data(), again.size() * 4, hipMemcpyHostToDevice, stream));
+			R.scratch = retryScratch;
+			R.job_list = retryList;
+			R.n_jobs = (uint32_t)again.size();
+			HIP_OK(hipMemsetAsync(R.next_job, 0, 16, stream));
+			hipEvent_t a, b;
+			HIP_OK(hipEventCreate(&a));
+			HIP_OK(hipEventCreate(&b));
+			HIP_OK(hipEventRecord(a, stream));
+			hipLaunchKernelGGL(ga_extend_kernel<256>, dim3(rslots), dim3(64), 0, stream, R);
+			HIP_OK(hipGetLastError());
+			HIP_OK(hipEventRecord(b, stream));
+			HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));
+			HIP_OK(hipStreamSynchronize(stream));
+			float ms2 = 0;
+			HIP_OK(hipEventElapsedTime(&ms2, a, b));
+			st.kernel_ms += ms2;
+			hipEventDestroy(a);
+			hipEventDestroy(b);
+		}
+		return 0;
+	}
+
+	int fetch(std::vector<GaJobOut>& o, std::vector<GaTraceStep>& traces, std::vector<uint64_t>& off) override
+	{
+		HIP_OK(hipSetDevice(g->device));
+		o = outs;
+		uint64_t top = 0;
+		HIP_OK(hipMemcpy(&top, L.trace_top, 8, hipMemcpyDeviceToHost));
+		top = std::min<uint64_t>(top, L.trace_pool_cap);
+		traces.resize(top);
+		if (top) HIP_OK(hipMemcpy(traces.data(), L.traces, top * sizeof(GaTraceStep), hipMemcpyDeviceToHost));
+		off.resize(outs.size());
+		for (size_t i = 0; i < outs.size(); i++) off[i] = outs[i].trace_off;
+		return 0;
+	}
+	GaRunStats stats() const override { return st; }
+};
+
+}  // namespace
+
+GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTables& hmm, int device, int* status)
+{
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) { *status = GA_E_NO_DEVICE; return nullptr; }
+	if (hipSetDevice(device) != hipSuccess) { *status = GA_E_NO_DEVICE; return nullptr; }
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { *status = GA_E_NO_DEVICE; return nullptr; }
+	DevGraph* g = new DevGraph();
+	g->device = device;
+	g->cus = prop.multiProcessorCount;
+	g->g.n_nodes = (uint32_t)(flat.node_start.size() - 1);
+	g->g.reserved = 0;
+	int bad = 0;
+	bad |= g->put(flat.node_start, &g->g.node_start);
+	bad |= g->put(flat.seq2, &g->g.seq2);
+	bad |= g->put(flat.in_off, &g->g.in_off);
+	bad |= g->put(flat.in_nbr, &g->g.in_nbr);
+	bad |= g->put(flat.out_off, &g->g.out_off);
+	bad |= g->put(flat.out_nbr, &g->g.out_nbr);
+	std::vector<GaHmmTables> h(1, hmm);
+	const GaHmmTables* dh = nullptr;
+	bad |= g->put(h, &dh);
+	g->hmm = const_cast<GaHmmTables*>(dh);
+	if (bad) { delete g; *status = GA_E_DEVICE; return nullptr; }
+	*status = 0;
+	return g;
+}
+
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, const std::vector<uint8_t>& rows, const std::vector<GaJob>& jobs,
+                                        const GaRunConfig& cfg, int* status)
+{
+	DevBatch* b = new DevBatch();
+	b->g = static_cast<DevGraph*>(graph);
+	b->cfg = cfg;
+	int s = b->init(rows, jobs);
+	if (s) { delete b; *status = s; return nullptr; }
+	*status = 0;
+	return b;
+}

@@ -1,0 +1,782 @@
+// ga_host.cpp -- host side of the C ABI (include/graphaligner_amd.h): the graph model the
+// reference's loaders build (AlignmentGraph.cpp, BigraphToDigraph.cpp), splitting reads into
+// extension jobs (GraphAligner.h:2969-3024), and turning the device's raw traces back into
+// AlignmentResults (GraphAligner.h:408-491, 594-847, 3026-3098).  No alignment arithmetic
+// happens here; the extension program runs behind ga_backend.h on the GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/graphaligner_amd.h"
+#include "ga_backend.h"
+
+namespace {
+
+constexpr int W = 64;
+
+// ---- character tables ------------------------------------------------------------------------
+struct CharTables
+{
+	uint8_t rowCode[256];    // bits 0-3: which of A,C,G,T the read char matches; bits 4-6: exact code; bit 7: not IUPAC
+	uint8_t complement[256]; // 0 = the reference's ReverseComplement asserts on this char
+	uint8_t baseCode[256];   // A0 C1 G2 T3, 255 otherwise
+	CharTables()
+	{
+		for (int c = 0; c < 256; c++) { rowCode[c] = GA_ROW_INVALID; complement[c] = 0; baseCode[c] = 255; }
+		auto setMatch = [&](char upper, int mask) {
+			rowCode[(uint8_t)upper] = (uint8_t)(mask | (7 << 4));
+			rowCode[(uint8_t)(upper + 32)] = (uint8_t)(mask | (7 << 4));
+		};
+		const int A = 1, C = 2, G = 4, T = 8;
+		// characterMatch (GraphAligner.h:2039-2110)
+		setMatch('A', A); setMatch('C', C); setMatch('G', G); setMatch('T', T); setMatch('N', A | C | G | T);
+		setMatch('R', A | G); setMatch('Y', C | T); setMatch('K', G | T); setMatch('M', C | A); setMatch('S', C | G); setMatch('W', A | T);
+		setMatch('B', C | G | T); setMatch('D', A | G | T); setMatch('H', A | C | T); setMatch('V', A | C | G);
+		// the "previousEq" comparison is a raw char == against the upper-case graph base (:1503,1540)
+		rowCode[(uint8_t)'A'] = (uint8_t)(A | (0 << 4)); rowCode[(uint8_t)'C'] = (uint8_t)(C | (1 << 4));
+		rowCode[(uint8_t)'G'] = (uint8_t)(G | (2 << 4)); rowCode[(uint8_t)'T'] = (uint8_t)(T | (3 << 4));
+		baseCode[(uint8_t)'A'] = 0; baseCode[(uint8_t)'C'] = 1; baseCode[(uint8_t)'G'] = 2; baseCode[(uint8_t)'T'] = 3;
+		// ReverseComplement (CommonUtils.cpp:60-136): 'H'/'h' fall through to assert(false); 'U' -> 'A'
+		const char* from = "ACTGNURYKMSWBVD";
+		const char* to = "TGACNAYRMKSWVBH";
+		for (int i = 0; from[i]; i++) { complement[(uint8_t)from[i]] = (uint8_t)to[i]; complement[(uint8_t)(from[i] + 32)] = (uint8_t)to[i]; }
+	}
+};
+const CharTables& tables() { static const CharTables t; return t; }
+
+GaHmmTables buildHmm()
+{
+	// AlignmentCorrectnessEstimation.cpp:6-36, 61-69, 81-83 -- same libm calls, same order
+	GaHmmTables t;
+	const double cMis = log(0.2), cMat = log(1.0 - 0.2), fMis = log(0.5), fMat = log(1.0 - 0.5);
+	t.f2c = log(0.00001); t.f2f = log(1.0 - 0.00001);
+	t.c2f = log(0.000000000000001); t.c2c = log(1.0 - 0.000000000000001);
+	double lf[65];
+	lf[0] = 0;
+	for (int i = 1; i <= 64; i++) lf[i] = lf[i - 1] + log(i);
+	for (int m = 0; m <= 64; m++)
+	{
+		double choose = lf[64] - lf[m] - lf[64 - m];
+		t.correct_mult[m] = choose + m * cMis + (64 - m) * cMat;
+		t.wrong_mult[m] = choose + m * fMis + (64 - m) * fMat;
+	}
+	t.init_correct = log(0.8);
+	t.init_wrong = log(0.2);
+	return t;
+}
+
+}  // namespace
+
+// ================================================================================================
+// graph
+// ================================================================================================
+struct ga_graph
+{
+	int dbgOverlap = 0;
+	bool finalized = false;
+	std::vector<uint64_t> nodeStart;
+	std::unordered_map<int64_t, uint32_t> lookup;
+	std::vector<int64_t> ids;
+	std::vector<std::vector<uint32_t>> in, out;
+	std::vector<uint8_t> reverse;
+	std::vector<uint8_t> bases;         // 0..3, 4 for the dummy columns
+	GaFlatGraph flat;
+	GaHmmTables hmm;
+	GaBackendGraph* device = nullptr;
+
+	ga_graph()
+	{
+		// dummy start node, one column (AlignmentGraph.cpp:22-30)
+		ids.push_back(0); nodeStart.push_back(0); in.emplace_back(); out.emplace_back(); reverse.push_back(0); bases.push_back(4);
+	}
+	uint32_t nodeCount() const { return (uint32_t)nodeStart.size(); }
+	uint64_t nodeEnd(uint32_t n) const { return n + 1 == nodeStart.size() ? bases.size() : nodeStart[n + 1]; }
+	uint32_t nodeLen(uint32_t n) const { return (uint32_t)(nodeEnd(n) - nodeStart[n]); }
+	char baseChar(uint32_t node, uint32_t offset) const { uint8_t b = bases[nodeStart[node] + offset]; return b < 4 ? "ACGT"[b] : '-'; }
+	int reverseNode(uint32_t n, uint32_t& outNode) const
+	{
+		// GetReverseNode (AlignmentGraph.cpp:199-214)
+		int64_t big = ids[n] / 2;
+		auto it = lookup.find(ids[n] % 2 == 1 ? big * 2 : big * 2 + 1);
+		if (it == lookup.end() || it->second == n || nodeLen(it->second) != nodeLen(n)) return GA_S_ASSERTION;
+		outNode = it->second;
+		return GA_S_OK;
+	}
+};
+
+static int addNode(ga_graph* g, int64_t id, const char* seq, size_t len, bool rev)
+{
+	if (g->finalized) return GA_E_INVALID;
+	if (g->lookup.count(id)) return GA_S_OK;            // duplicates ignored (AlignmentGraph.cpp:51)
+	for (size_t i = 0; i < len; i++) if (tables().baseCode[(uint8_t)seq[i]] > 3) return GA_E_INVALID;   // graph is ACGT only (:83-85)
+	if (g->nodeStart.size() >= 0x7ffffff0u) return GA_E_INVALID;
+	g->lookup[id] = (uint32_t)g->nodeStart.size();
+	g->ids.push_back(id);
+	g->nodeStart.push_back(g->bases.size());
+	g->in.emplace_back();
+	g->out.emplace_back();
+	g->reverse.push_back(rev ? 1 : 0);
+	for (size_t i = 0; i < len; i++) g->bases.push_back(tables().baseCode[(uint8_t)seq[i]]);
+	return GA_S_OK;
+}
+
+static int addEdge(ga_graph* g, int64_t from, int64_t to)
+{
+	if (g->finalized) return GA_E_INVALID;
+	auto f = g->lookup.find(from), t = g->lookup.find(to);
+	if (f == g->lookup.end() || t == g->lookup.end()) return GA_E_INVALID;
+	auto& inl = g->in[t->second];
+	auto& outl = g->out[f->second];
+	if (std::find(inl.begin(), inl.end(), f->second) == inl.end()) inl.push_back(f->second);      // no double edges (:104-105)
+	if (std::find(outl.begin(), outl.end(), t->second) == outl.end()) outl.push_back(t->second);
+	return GA_S_OK;
+}
+
+static std::string revcompACGT(const char* seq, size_t len)
+{
+	std::string r(len, 'N');
+	for (size_t i = 0; i < len; i++) r[i] = (char)tables().complement[(uint8_t)seq[len - 1 - i]];
+	return r;
+}
+
+static int finalizeGraph(ga_graph* g, int overlap)
+{
+	if (g->finalized) return GA_E_INVALID;
+	g->dbgOverlap = overlap;
+	// dummy end node (AlignmentGraph.cpp:110-118)
+	g->ids.push_back(0); g->nodeStart.push_back(g->bases.size()); g->reverse.push_back(0); g->in.emplace_back(); g->out.emplace_back(); g->bases.push_back(4);
+	g->finalized = true;
+	const uint32_t n = g->nodeCount();
+	GaFlatGraph& f = g->flat;
+	f.node_start.assign(g->nodeStart.begin(), g->nodeStart.end());
+	f.node_start.push_back(g->bases.size());
+	f.seq2.assign((g->bases.size() + 15) / 16 + 1, 0);
+	for (size_t i = 0; i < g->bases.size(); i++) f.seq2[i >> 4] |= (uint32_t)(g->bases[i] & 3) << ((i & 15) * 2);
+	f.in_off.assign(n + 1, 0);
+	f.out_off.assign(n + 1, 0);
+	for (uint32_t i = 0; i < n; i++) { f.in_off[i + 1] = f.in_off[i] + (uint32_t)g->in[i].size(); f.out_off[i + 1] = f.out_off[i] + (uint32_t)g->out[i].size(); }
+	f.in_nbr.reserve(f.in_off[n] + 1);
+	f.out_nbr.reserve(f.out_off[n] + 1);
+	for (uint32_t i = 0; i < n; i++) { f.in_nbr.insert(f.in_nbr.end(), g->in[i].begin(), g->in[i].end()); f.out_nbr.insert(f.out_nbr.end(), g->out[i].begin(), g->out[i].end()); }
+	f.in_nbr.push_back(0);
+	f.out_nbr.push_back(0);
+	g->hmm = buildHmm();
+	return GA_S_OK;
+}
+
+// ================================================================================================
+// jobs and results
+// ================================================================================================
+namespace {
+
+struct Pos { uint32_t node, offset; uint64_t row; };
+typedef std::vector<Pos> Trace;
+
+struct SeedPlan
+{
+	bool valid = false;          // lookups succeeded and the position is inside the read
+	int early = GA_S_OK;         // status fixed before any device work (bad seed, assertion while splitting)
+	uint32_t seedNodeIndex = 0;  // nodeLookup.at(id * 2), what the "already aligned" test compares (GraphAligner.h:423-425)
+	int64_t fwJob = -1, bwJob = -1;
+	uint64_t pos = 0;
+};
+
+struct ReadPlan { size_t firstSeed = 0, nSeeds = 0; };
+
+struct Partial { bool failed = true; int32_t score = 0; std::vector<ga_mapping_t> maps; std::vector<std::string> seqs; };
+
+}  // namespace
+
+struct ga_batch
+{
+	const ga_graph* g = nullptr;
+	std::vector<std::string> names, seqs;
+	std::vector<ReadPlan> reads;
+	std::vector<SeedPlan> seeds;
+	std::vector<uint8_t> rows;
+	std::vector<GaJob> jobs;
+	GaRunConfig cfg;
+	uint32_t flags = 0;
+	GaBackendBatch* dev = nullptr;
+	bool ran = false;
+	uint64_t columnUpdates = 0, slicesRun = 0;
+	~ga_batch() { delete dev; }
+};
+
+namespace {
+
+struct ResultsOwner
+{
+	ga_results_t pub;
+	std::vector<ga_read_result_t> reads;
+	std::vector<ga_mapping_t> mappings;
+	std::vector<char> edits;
+	std::vector<ga_trace_item_t> trace;
+};
+
+int mapDeviceStatus(int s)
+{
+	switch (s)
+	{
+		case GA_OK: return GA_S_OK;
+		case GA_ASSERTION: return GA_S_ASSERTION;
+		case GA_UNSUPPORTED_BAND: return GA_S_UNSUPPORTED_BAND;
+		case GA_UNSUPPORTED_CYCLE: return GA_S_UNSUPPORTED_CYCLE;
+		case GA_UNSUPPORTED_RAMP: return GA_S_UNSUPPORTED_RAMP;
+		case GA_CAP_NODES: case GA_CAP_COLS: case GA_CAP_ARENA: case GA_CAP_TRACE: case GA_CAP_HEAP: return GA_S_CAPACITY;
+		default: return GA_E_DEVICE;
+	}
+}
+
+// traceToAlignment (GraphAligner.h:782-847).  Node indices come straight from the device trace.
+Partial toMappings(const ga_graph& g, const std::string& sequence, int32_t score, const Trace& trace)
+{
+	Partial res;
+	res.score = score;
+	res.failed = false;
+	if (trace.empty()) { res.failed = true; return res; }
+	size_t pos = 0;
+	uint32_t oldNode = trace[0].node;
+	while (oldNode == 0)                                    // dummyNodeStart
+	{
+		pos++;
+		if (pos == trace.size()) { res.failed = true; res.score = std::numeric_limits<int32_t>::max(); return res; }
+		oldNode = trace[pos].node;
+	}
+	const uint64_t dummyEndAsIndex = g.bases.size() - 1;   // (sic) the reference compares a node index with a column index (:802,816)
+	if (oldNode == dummyEndAsIndex) { res.failed = true; res.score = std::numeric_limits<int32_t>::max(); return res; }
+	int rank = 0;
+	ga_mapping_t m;
+	memset(&m, 0, sizeof(m));
+	m.rank = rank; m.node_id = g.ids[oldNode]; m.is_reverse = g.reverse[oldNode]; m.offset = trace[pos].offset;
+	Pos nodeStart = trace[pos], nodeEnd = trace[pos], beforeNode = trace[pos];
+	auto column = [&](const Pos& p) { return g.nodeStart[p.node] + p.offset; };
+	for (; pos < trace.size(); pos++)
+	{
+		if (trace[pos].node == dummyEndAsIndex) break;
+		if (trace[pos].node == oldNode) { nodeEnd = trace[pos]; continue; }
+		m.from_length = (int64_t)(column(nodeEnd) - column(nodeStart) + 1);
+		m.to_length = (int64_t)(nodeEnd.row - beforeNode.row);
+		res.maps.push_back(m);
+		res.seqs.push_back(sequence.substr(nodeStart.row, nodeEnd.row - beforeNode.row));
+		oldNode = trace[pos].node;
+		beforeNode = nodeEnd;
+		nodeStart = trace[pos];
+		nodeEnd = trace[pos];
+		rank++;
+		memset(&m, 0, sizeof(m));
+		m.rank = rank; m.node_id = g.ids[oldNode]; m.is_reverse = g.reverse[oldNode];
+	}
+	m.from_length = (int64_t)(column(nodeEnd) - column(nodeStart));        // no +1 on the last mapping (:843)
+	m.to_length = (int64_t)(nodeEnd.row - beforeNode.row);
+	res.maps.push_back(m);
+	res.seqs.push_back(sequence.substr(nodeStart.row, nodeEnd.row - beforeNode.row));
+	return res;
+}
+
+// mergeAlignments (GraphAligner.h:648-688): backward part first, then forward
+Partial mergePartials(const ga_graph& g, const Partial& first, const Partial& second)
+{
+	if (first.failed) return second;
+	if (second.failed) return first;
+	if (first.maps.empty()) return second;
+	if (second.maps.empty()) return first;
+	Partial out;
+	out.failed = false;
+	out.maps = first.maps;
+	out.seqs = first.seqs;
+	out.score = first.score + second.score;
+	size_t startAt = 0;
+	const ga_mapping_t& a = first.maps.back();
+	const ga_mapping_t& b = second.maps.front();
+	uint32_t an = g.lookup.at(a.node_id), bn = g.lookup.at(b.node_id);
+	if (a.node_id == b.node_id && a.is_reverse == b.is_reverse) startAt = 1;
+	else if (std::find(g.out[an].begin(), g.out[an].end(), bn) != g.out[an].end()) startAt = 0;
+	for (size_t i = startAt; i < second.maps.size(); i++) { out.maps.push_back(second.maps[i]); out.seqs.push_back(second.seqs[i]); }
+	return out;
+}
+
+bool readMatches(char readChar, char graphChar)
+{
+	uint8_t code = tables().rowCode[(uint8_t)readChar];
+	uint8_t b = tables().baseCode[(uint8_t)graphChar];
+	return b < 4 && ((code >> b) & 1);
+}
+
+// getTraceInfoInner (GraphAligner.h:718-780).  Returns false where the reference's characterMatch
+// would assert: a diagonal step over a read character that is not IUPAC (e.g. 'U'), which can
+// survive the backward split because ReverseComplement maps it (CommonUtils.cpp:85-88).
+bool traceItemsInner(const ga_graph& g, const std::string& seq, const Trace& tr, std::vector<ga_trace_item_t>& out)
+{
+	for (size_t i = 1; i < tr.size(); i++)
+	{
+		const Pos& now = tr[i];
+		const Pos& old = tr[i - 1];
+		bool sameColumn = now.node == old.node && now.offset == old.offset;
+		bool diagonal = now.row != old.row;
+		if (sameColumn)
+		{
+			const auto& outs = g.out[now.node];
+			bool selfLoop = now.row == old.row + 1 && g.nodeLen(now.node) == 1 && std::find(outs.begin(), outs.end(), now.node) != outs.end();
+			if (!selfLoop) diagonal = false;
+		}
+		ga_trace_item_t it;
+		memset(&it, 0, sizeof(it));
+		it.node_id = (int32_t)(g.ids[now.node] / 2);
+		it.reverse = g.ids[now.node] % 2 == 1;
+		it.offset = now.offset;
+		it.read_pos = now.row;
+		it.graph_char = g.baseChar(now.node, now.offset);
+		it.read_char = seq[now.row];
+		if (now.row == old.row) it.type = 4;
+		else if (sameColumn && !diagonal) it.type = 3;
+		else
+		{
+			if (tables().rowCode[(uint8_t)seq[now.row]] & GA_ROW_INVALID) return false;
+			it.type = readMatches(seq[now.row], it.graph_char) ? 1 : 2;
+		}
+		out.push_back(it);
+	}
+	return true;
+}
+
+// getTraceInfo (GraphAligner.h:690-716)
+bool traceItems(const ga_graph& g, const std::string& seq, const Trace& bw, const Trace& fw, std::vector<ga_trace_item_t>& out)
+{
+	if (!bw.empty() && !traceItemsInner(g, seq, bw, out)) return false;
+	if (!bw.empty() && !fw.empty())
+	{
+		ga_trace_item_t it;
+		memset(&it, 0, sizeof(it));
+		it.type = 5;
+		it.node_id = (int32_t)(g.ids[fw[0].node] / 2);
+		it.reverse = fw[0].node % 2 == 1;                   // node INDEX parity, as in the reference (:704)
+		it.offset = fw[0].offset;
+		it.read_pos = fw[0].row;
+		it.graph_char = g.baseChar(fw[0].node, fw[0].offset);
+		it.read_char = seq[fw[0].row];
+		out.push_back(it);
+	}
+	if (!fw.empty() && !traceItemsInner(g, seq, fw, out)) return false;
+	return true;
+}
+
+// addAlignmentNodes (GraphAligner.h:594-634)
+void noteTried(std::vector<std::tuple<uint64_t, uint64_t, uint32_t>>& tried, const Trace& t)
+{
+	if (t.empty()) return;
+	uint32_t oldNode = t[0].node;
+	uint64_t lo = t[0].row, hi = t[0].row;
+	for (size_t i = 1; i < t.size(); i++)
+	{
+		if (t[i].node != oldNode)
+		{
+			tried.emplace_back(lo, hi, oldNode);
+			lo = t[i].row;
+			oldNode = t[i].node;
+		}
+		hi = t[i].row;
+	}
+	tried.emplace_back(lo, hi, oldNode);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+ga_graph_t* ga_graph_create(void) { return new ga_graph(); }
+void ga_graph_destroy(ga_graph_t* g) { if (g) { delete g->device; delete g; } }
+int ga_graph_add_node(ga_graph_t* g, int64_t id, const char* seq, size_t len, int rev) { return g ? addNode(g, id, seq, len, rev != 0) : GA_E_INVALID; }
+int ga_graph_add_edge(ga_graph_t* g, int64_t from, int64_t to) { return g ? addEdge(g, from, to) : GA_E_INVALID; }
+int ga_graph_add_bigraph_node(ga_graph_t* g, int64_t id, const char* seq, size_t len)
+{
+	if (!g) return GA_E_INVALID;
+	int s = addNode(g, id * 2, seq, len, false);
+	if (s) return s;
+	std::string rc = revcompACGT(seq, len);
+	return addNode(g, id * 2 + 1, rc.data(), rc.size(), true);
+}
+int ga_graph_add_bigraph_edge(ga_graph_t* g, int64_t from, int fromStart, int64_t to, int toEnd)
+{
+	if (!g) return GA_E_INVALID;
+	// BigraphToDigraph.cpp:32-56 / 70-104
+	int64_t fromLeft = fromStart ? from * 2 : from * 2 + 1, fromRight = fromStart ? from * 2 + 1 : from * 2;
+	int64_t toLeft = toEnd ? to * 2 : to * 2 + 1, toRight = toEnd ? to * 2 + 1 : to * 2;
+	int s = addEdge(g, fromRight, toRight);
+	if (s) return s;
+	return addEdge(g, toLeft, fromLeft);
+}
+int ga_graph_finalize(ga_graph_t* g, int overlap) { return g ? finalizeGraph(g, overlap) : GA_E_INVALID; }
+
+int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len)
+{
+	// DirectedGraph::StreamGFAGraphFromFile (BigraphToDigraph.cpp:137-189): three passes over the lines
+	if (!g || g->finalized) return GA_E_INVALID;
+	std::vector<std::pair<const char*, size_t>> lines;
+	for (size_t i = 0; i < len;)
+	{
+		size_t e = i;
+		while (e < len && text[e] != '\n') e++;
+		if (e > i) lines.emplace_back(text + i, e - i);
+		i = e + 1;
+	}
+	int overlap = 0;
+	for (auto& l : lines)
+	{
+		if (l.first[0] != 'L') continue;
+		std::stringstream str(std::string(l.first, l.second));
+		std::string d1, d2, d3, d4, d5, ov;
+		str >> d1 >> d2 >> d3 >> d4 >> d5 >> ov;
+		if (ov.size() < 2) return GA_E_INVALID;
+		int o = std::stoi(ov.substr(0, ov.size() - 1));
+		if (!(overlap == 0 || overlap == o)) return GA_E_INVALID;
+		overlap = o;
+	}
+	for (auto& l : lines)
+	{
+		if (l.first[0] != 'S') continue;
+		std::stringstream str(std::string(l.first, l.second));
+		std::string d, seq;
+		int64_t id;
+		str >> d >> id >> seq;
+		if ((int)seq.size() <= overlap) return GA_E_INVALID;
+		size_t keep = seq.size() - overlap;
+		int s = addNode(g, id * 2, seq.data(), keep, false);
+		if (s) return s;
+		std::string rc = revcompACGT(seq.data(), seq.size());
+		s = addNode(g, id * 2 + 1, rc.data(), keep, true);
+		if (s) return s;
+	}
+	for (auto& l : lines)
+	{
+		if (l.first[0] != 'L') continue;
+		std::stringstream str(std::string(l.first, l.second));
+		std::string d, fs, te;
+		int64_t from, to;
+		str >> d >> from >> fs >> to >> te;
+		if ((fs != "+" && fs != "-") || (te != "+" && te != "-")) return GA_E_INVALID;
+		int s = ga_graph_add_bigraph_edge(g, from, fs == "-", to, te == "-");
+		if (s) return s;
+	}
+	return finalizeGraph(g, overlap);
+}
+
+int ga_graph_upload(ga_graph_t* g, int device)
+{
+	if (!g) return GA_E_INVALID;
+	if (!g->finalized) return GA_E_NOT_FINALIZED;
+	delete g->device;
+	int status = GA_S_OK;
+	g->device = ga_backend_upload_graph(g->flat, g->hmm, device, &status);
+	return g->device ? GA_S_OK : (status ? status : GA_E_DEVICE);
+}
+int64_t ga_graph_node_count(const ga_graph_t* g) { return g ? g->nodeCount() : 0; }
+int64_t ga_graph_bp(const ga_graph_t* g) { return g ? (int64_t)g->bases.size() : 0; }
+
+int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads, const ga_seed_t* seeds, const size_t* seedOffsets,
+                     int initialBandwidth, int rampBandwidth, uint32_t flags, ga_batch_t** out)
+{
+	if (!g || !out || (!reads && nReads) || !seedOffsets) return GA_E_INVALID;
+	if (!g->finalized) return GA_E_NOT_FINALIZED;
+	if (!g->device) return GA_E_NO_DEVICE;
+	const CharTables& T = tables();
+	ga_batch* b = new ga_batch();
+	b->g = g;
+	b->flags = flags;
+	b->cfg.initial_bw = initialBandwidth;
+	b->cfg.ramp_bw = rampBandwidth;
+	b->reads.resize(nReads);
+	b->names.resize(nReads);
+	b->seqs.resize(nReads);
+	auto pad64 = [](uint64_t n) { return (n + W - 1) / W * W; };
+	for (size_t i = 0; i < nReads; i++)
+	{
+		b->names[i] = reads[i].name ? reads[i].name : "";
+		b->seqs[i].assign(reads[i].sequence, reads[i].length);
+		const std::string& seq = b->seqs[i];
+		b->reads[i].firstSeed = b->seeds.size();
+		b->reads[i].nSeeds = seedOffsets[i + 1] - seedOffsets[i];
+		for (size_t k = seedOffsets[i]; k < seedOffsets[i + 1]; k++)
+		{
+			SeedPlan sp;
+			sp.pos = seeds[k].read_pos;
+			const int64_t id = seeds[k].node_id;
+			auto plain = g->lookup.find(id * 2);
+			auto flipped = g->lookup.find(id * 2 + 1);
+			if (plain == g->lookup.end() || flipped == g->lookup.end()) { sp.early = GA_S_BAD_SEED; b->seeds.push_back(sp); continue; }
+			sp.seedNodeIndex = plain->second;
+			// getSplitAlignment (GraphAligner.h:2969-3024)
+			if (!(sp.pos < seq.size())) { sp.early = GA_S_ASSERTION; b->seeds.push_back(sp); continue; }
+			uint32_t fwNode = seeds[k].reverse ? flipped->second : plain->second;
+			uint32_t bwNode = seeds[k].reverse ? plain->second : flipped->second;
+			if (g->nodeLen(fwNode) != g->nodeLen(bwNode)) { sp.early = GA_S_ASSERTION; b->seeds.push_back(sp); continue; }
+			sp.valid = true;
+			if (sp.pos > 0)
+			{
+				if (seq.size() < sp.pos + (uint64_t)g->dbgOverlap) { sp.early = GA_S_ASSERTION; sp.valid = false; b->seeds.push_back(sp); continue; }
+				uint64_t n = sp.pos + g->dbgOverlap;
+				// ReverseComplement asserts on anything outside its table, eagerly over the whole prefix (CommonUtils.cpp:60-136)
+				bool bad = false;
+				for (uint64_t r = 0; r < n; r++) if (!T.complement[(uint8_t)seq[r]]) { bad = true; break; }
+				if (bad) { sp.early = GA_S_ASSERTION; sp.valid = false; b->seeds.push_back(sp); continue; }
+				GaJob job;
+				job.rows_off = b->rows.size();
+				job.n_rows = (uint32_t)pad64(n);
+				job.seed_node = bwNode;
+				b->rows.resize(b->rows.size() + job.n_rows, T.rowCode[(uint8_t)'N']);
+				uint8_t* dst = b->rows.data() + job.rows_off;
+				for (uint64_t r = 0; r < n; r++) dst[r] = T.rowCode[T.complement[(uint8_t)seq[n - 1 - r]]];
+				sp.bwJob = (int64_t)b->jobs.size();
+				b->jobs.push_back(job);
+			}
+			if (sp.pos < seq.size() - 1)
+			{
+				uint64_t n = seq.size() - sp.pos;
+				GaJob job;
+				job.rows_off = b->rows.size();
+				job.n_rows = (uint32_t)pad64(n);
+				job.seed_node = fwNode;
+				b->rows.resize(b->rows.size() + job.n_rows, T.rowCode[(uint8_t)'N']);
+				uint8_t* dst = b->rows.data() + job.rows_off;
+				for (uint64_t r = 0; r < n; r++) dst[r] = T.rowCode[(uint8_t)seq[sp.pos + r]];
+				sp.fwJob = (int64_t)b->jobs.size();
+				b->jobs.push_back(job);
+			}
+			b->seeds.push_back(sp);
+		}
+	}
+	for (const GaJob& j : b->jobs)
+	{
+		b->cfg.max_rows = std::max(b->cfg.max_rows, j.n_rows);
+		b->cfg.max_slices = std::max(b->cfg.max_slices, j.n_rows / W);
+	}
+	b->rows.resize(b->rows.size() + 64, 0);     // slack so a 64-byte row load never leaves the buffer
+	int status = GA_S_OK;
+	b->dev = ga_backend_create_batch(g->device, b->rows, b->jobs, b->cfg, &status);
+	if (!b->dev) { delete b; return status ? status : GA_E_DEVICE; }
+	*out = b;
+	return GA_S_OK;
+}
+
+int ga_batch_run(ga_batch_t* b)
+{
+	if (!b || !b->dev) return GA_E_INVALID;
+	int s = b->dev->run();
+	b->ran = s == GA_S_OK;
+	return s;
+}
+
+int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out)
+{
+	if (!b || !out || !b->dev) return GA_E_INVALID;
+	memset(out, 0, sizeof(*out));
+	GaRunStats st = b->dev->stats();
+	out->n_jobs = b->jobs.size();
+	out->kernel_ms = st.kernel_ms;
+	out->slots = st.slots;
+	out->waves_per_cu = st.waves_per_cu;
+	out->scratch_bytes = st.scratch_bytes;
+	out->jobs_retried = st.jobs_retried;
+	out->column_updates = b->columnUpdates;
+	out->slices = b->slicesRun;
+	return GA_S_OK;
+}
+
+int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
+{
+	if (!b || !out || !b->dev || !b->ran) return GA_E_INVALID;
+	const ga_graph& g = *b->g;
+	std::vector<GaJobOut> outs;
+	std::vector<GaTraceStep> steps;
+	std::vector<uint64_t> stepOff;
+	int s = b->dev->fetch(outs, steps, stepOff);
+	if (s) return s;
+	b->columnUpdates = 0;
+	b->slicesRun = 0;
+	for (const GaJobOut& o : outs) { b->columnUpdates += o.n_columns; b->slicesRun += o.n_run; }
+	ResultsOwner* R = new ResultsOwner();
+	R->reads.resize(b->reads.size());
+	const int32_t kMax = std::numeric_limits<int32_t>::max();
+
+	// device order is backwards (last row first) and ends with the row "-1" entry
+	// (getTraceFromTable :949-952 pops it and reverses)
+	auto deviceTrace = [&](int64_t job) {
+		Trace t;
+		const GaJobOut& o = outs[job];
+		if (o.n_valid == 0 || o.trace_len < 2) return t;
+		const GaTraceStep* p = steps.data() + stepOff[job];
+		t.resize(o.trace_len - 1);
+		for (uint32_t i = 0; i + 1 < o.trace_len; i++)
+		{
+			const GaTraceStep& st = p[o.trace_len - 2 - i];
+			t[i] = Pos{st.node, st.offset, st.row};
+		}
+		return t;
+	};
+
+	for (size_t ri = 0; ri < b->reads.size(); ri++)
+	{
+		ga_read_result_t& rr = R->reads[ri];
+		memset(&rr, 0, sizeof(rr));
+		rr.failed = 1;
+		rr.score = kMax;
+		rr.first_mapping = R->mappings.size();
+		rr.first_trace = R->trace.size();
+		const std::string& seq = b->seqs[ri];
+		const ReadPlan& rp = b->reads[ri];
+		if (rp.nSeeds == 0) { rr.status = GA_S_ASSERTION; continue; }          // assert(seedHits.size() > 0) (:412)
+		std::vector<std::tuple<uint64_t, uint64_t, uint32_t>> tried;
+		bool have = false;
+		uint64_t bestEstimate = 0, bestPos = 0;
+		Trace bestFw, bestBw;
+		int32_t bestFwScore = 0, bestBwScore = 0;
+		int status = GA_S_OK;
+		for (size_t k = rp.firstSeed; k < rp.firstSeed + rp.nSeeds && status == GA_S_OK; k++)
+		{
+			const SeedPlan& sp = b->seeds[k];
+			if (sp.early == GA_S_BAD_SEED) { status = GA_S_BAD_SEED; break; }
+			bool covered = false;
+			for (auto& t : tried) if (std::get<0>(t) <= sp.pos && std::get<1>(t) >= sp.pos && std::get<2>(t) == sp.seedNodeIndex) { covered = true; break; }
+			if (covered) continue;                                               // "seed already aligned" (:425-429)
+			if (sp.early != GA_S_OK) { status = sp.early; break; }
+			uint64_t nValidFw = 0, nValidBw = 0;
+			for (int64_t job : {sp.bwJob, sp.fwJob})
+			{
+				if (job < 0) continue;
+				rr.column_updates += outs[job].n_columns;
+				if (outs[job].status != GA_OK) status = mapDeviceStatus(outs[job].status);
+			}
+			if (status != GA_S_OK) break;
+			if (sp.fwJob >= 0) nValidFw = outs[sp.fwJob].n_valid;
+			if (sp.bwJob >= 0) nValidBw = outs[sp.bwJob].n_valid;
+			// getPiecewiseTracesFromSplit (:3039-3098)
+			Trace fw, bw;
+			int32_t fwScore = 0, bwScore = 0;
+			if (sp.fwJob >= 0 && nValidFw > 0)
+			{
+				uint64_t traceable = seq.size() - sp.pos - g.dbgOverlap;
+				fw = deviceTrace(sp.fwJob);
+				fwScore = outs[sp.fwJob].score;
+				while (!fw.empty() && fw.back().row >= traceable) fw.pop_back();
+			}
+			if (sp.bwJob >= 0 && nValidBw > 0)
+			{
+				uint64_t traceable = sp.pos;
+				bw = deviceTrace(sp.bwJob);
+				bwScore = outs[sp.bwJob].score;
+				while (!bw.empty() && bw.back().row >= traceable) bw.pop_back();
+				// reverseTrace (:3026-3037)
+				std::reverse(bw.begin(), bw.end());
+				uint64_t endRow = sp.pos - 1;
+				for (auto& p : bw)
+				{
+					uint32_t other;
+					if (g.reverseNode(p.node, other) != GA_S_OK || p.row > endRow) { status = GA_S_ASSERTION; break; }
+					p.offset = g.nodeLen(other) - 1 - p.offset;
+					p.node = other;
+					p.row = endRow - p.row;
+				}
+				for (auto& p : fw) p.row += sp.pos;                            // only inside this branch (:3091-3094)
+			}
+			if (status != GA_S_OK) break;
+			noteTried(tried, fw);
+			noteTried(tried, bw);
+			uint64_t estimate = (nValidFw + nValidBw) * W;
+			if (!have || estimate > bestEstimate)
+			{
+				bestFw = std::move(fw); bestBw = std::move(bw); bestFwScore = fwScore; bestBwScore = bwScore;
+				bestEstimate = estimate; bestPos = sp.pos; have = true;
+			}
+		}
+		rr.status = status;
+		if (status != GA_S_OK || !have) continue;
+		size_t traceMark = R->trace.size();
+		// the reference always builds the TraceItem list (:463) and characterMatch asserts on a
+		// non-IUPAC read character; only reads that contain one need the scan when no trace is wanted
+		bool wantTrace = (b->flags & GA_F_TRACE) != 0;
+		bool suspicious = false;
+		if (!wantTrace) for (char c : seq) if (tables().rowCode[(uint8_t)c] & GA_ROW_INVALID) { suspicious = true; break; }
+		if (wantTrace || suspicious)
+		{
+			bool fine = traceItems(g, seq, bestBw, bestFw, R->trace);
+			if (!wantTrace || !fine) R->trace.resize(traceMark);
+			if (!fine) { rr.status = GA_S_ASSERTION; continue; }
+		}
+		Partial fwp = toMappings(g, seq, bestFwScore, bestFw);
+		Partial bwp = toMappings(g, seq, bestBwScore, bestBw);
+		if (fwp.failed && bwp.failed) { R->trace.resize(traceMark); continue; }
+		Partial merged = mergePartials(g, bwp, fwp);
+		rr.failed = 0;
+		rr.score = merged.score;
+		rr.n_mappings = merged.maps.size();
+		for (size_t i = 0; i < merged.maps.size(); i++)
+		{
+			ga_mapping_t m = merged.maps[i];
+			m.edit_seq_off = R->edits.size();
+			R->edits.insert(R->edits.end(), merged.seqs[i].begin(), merged.seqs[i].end());
+			R->mappings.push_back(m);
+		}
+		rr.n_trace = R->trace.size() - traceMark;
+		uint64_t lastAligned = !bestBw.empty() ? bestBw[0].row : bestPos;
+		rr.query_position = lastAligned;
+		rr.alignment_start = lastAligned;
+		rr.alignment_end = lastAligned + bestEstimate;
+	}
+	R->pub.n_reads = R->reads.size(); R->pub.reads = R->reads.data();
+	R->pub.n_mappings = R->mappings.size(); R->pub.mappings = R->mappings.data();
+	R->pub.n_edit_bytes = R->edits.size(); R->pub.edit_bytes = R->edits.data();
+	R->pub.n_trace = R->trace.size(); R->pub.trace = R->trace.data();
+	*out = &R->pub;
+	return GA_S_OK;
+}
+
+void ga_batch_free(ga_batch_t* b) { delete b; }
+
+void ga_results_free(ga_results_t* r)
+{
+	if (!r) return;
+	delete reinterpret_cast<ResultsOwner*>(r);     // `pub` is the owner's first member
+}
+
+int ga_align_batch(const ga_graph_t* g, const ga_read_t* reads, size_t nReads, const ga_seed_t* seeds, const size_t* seedOffsets,
+                   int initialBandwidth, int rampBandwidth, uint32_t flags, ga_results_t** out)
+{
+	ga_batch_t* b = nullptr;
+	int s = ga_batch_prepare(g, reads, nReads, seeds, seedOffsets, initialBandwidth, rampBandwidth, flags, &b);
+	if (s) return s;
+	s = ga_batch_run(b);
+	if (!s) s = ga_batch_collect(b, out);
+	ga_batch_free(b);
+	return s;
+}
+
+const char* ga_status_string(int s)
+{
+	switch (s)
+	{
+		case GA_S_OK: return "ok";
+		case GA_S_ASSERTION: return "reference assertion";
+		case GA_S_UNSUPPORTED_BAND: return "band >= 200000 bp (sparse method not built)";
+		case GA_S_BAD_SEED: return "seed node not in graph";
+		case GA_S_CAPACITY: return "device buffer capacity";
+		case GA_S_UNSUPPORTED_CYCLE: return "cyclic band (not built on device)";
+		case GA_S_UNSUPPORTED_RAMP: return "ramp redo (not built on device)";
+		case GA_E_INVALID: return "invalid argument";
+		case GA_E_NO_DEVICE: return "no gfx950 device / graph not uploaded";
+		case GA_E_DEVICE: return "device error";
+		case GA_E_NOT_FINALIZED: return "graph not finalized";
+	}
+	return "unknown";
+}
+const char* ga_version(void) { return "graphaligner_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,754 @@
+// ga_kernel.h -- the per-read extension program: one wavefront owns one read direction.
+//
+// What it computes is the reference's seeded extension (GraphAligner.h:2571-2856 first pass,
+// :894-1021 traceback), restated for a 64-lane wave:
+//   * lanes = the 64 read rows of a slice.  A graph column is 64 scores, one per lane; the
+//     column recurrence is   S(w,r) = min(S(w-1,r)+1, S(w-1,r-1)+mismatch, S(w,r-1)+1)
+//     evaluated as a horizontal/diagonal candidate per lane (one wave_shr DPP move) followed by
+//     a wave-wide prefix-min that resolves the vertical chain (GraphAligner.h:1349-1427 is the
+//     bit-vector form of the same recurrence).  Column merges (WordSlice.h:361-421) are
+//     plain per-lane minima.  VP/VN words fall out of two ballots.
+//   * band projection, processing order and traceback are wave-uniform scalar code whose
+//     data structures live in LDS; they reproduce the reference's ORDER (hash-map iteration
+//     of the frozen slice, std::priority_queue tie order, Tarjan emission order) because the
+//     trace start is the LAST minimum in processing order (GraphAligner.h:922,931).
+//   * one pass: every slice's VP/VN/score words are kept in HBM (20 B per column) and the
+//     traceback reads them directly, instead of the reference's sqrt-checkpoint + recompute.
+//
+// The same source builds for gfx950 (product) and, with GA_EMULATE, for the host (tests only).
+#pragma once
+#include "ga_types.h"
+#include "ga_wave.h"
+
+namespace gak {
+using namespace gaw;
+
+constexpr int W = 64;
+constexpr uint32_t kCutoff = 200000;         // GraphAlignerCommon.h:10
+constexpr int kSliceHdrWords = 6;
+
+template <int MAXN> struct Limits
+{
+	static constexpr int kBuckets = MAXN <= 13 ? 13 : MAXN <= 29 ? 29 : MAXN <= 59 ? 59 : MAXN <= 127 ? 127 : 257;   // libstdc++ growth: 13,29,59,127,257
+	static constexpr int kHeap = 6 * MAXN;
+	static_assert(MAXN <= 257, "bucket schedule only covers 257 band nodes");
+};
+
+// LDS-resident per-wave state
+template <int MAXN> struct WaveState
+{
+	// previous band, in band (insertion) order
+	uint32_t pn_node[MAXN];
+	int32_t pn_min[MAXN];        // node minimum of scoreEnd (NodeSlice MapItem<2>)
+	int32_t pn_lastEnd[MAXN];    // scoreEnd of the node's last column
+	int32_t pn_lastEnd2[MAXN];   // score one row above it (scoreEnd -/+ last VP/VN bit)
+	uint32_t pn_colBase[MAXN];   // first column of the node inside the previous end buffer
+	// current band, in band order
+	uint32_t cn_node[MAXN];
+	uint32_t cn_colBase[MAXN];
+	uint32_t cn_len[MAXN];
+	int16_t cn_prev[MAXN];       // slot in the previous band or -1
+	int32_t cn_min[MAXN];
+	int32_t cn_lastEnd[MAXN];
+	int32_t cn_lastEnd2[MAXN];
+	uint64_t cn_lastVP[MAXN];
+	uint64_t cn_lastVN[MAXN];
+	int32_t cn_lastBefore[MAXN];
+	uint8_t cn_lastExists[MAXN];
+	uint8_t color[MAXN];
+	int16_t post[MAXN];          // Tarjan emission order
+	// scratch: hash-order emulation / heap / DFS stack
+	int16_t h_next[MAXN];
+	int16_t h_before[Limits<MAXN>::kBuckets];
+	int16_t h_order[MAXN];
+	uint32_t heap_node[Limits<MAXN>::kHeap];
+	int32_t heap_prio[Limits<MAXN>::kHeap];
+	int16_t st_slot[MAXN];
+	uint32_t st_cur[MAXN];
+};
+
+struct Slot
+{
+	uint32_t* end_prev;      // packed (scoreEnd << 2 | vpLast | vnLast << 1) per column of the previous slice
+	uint32_t* end_cur;
+	uint32_t* arena;         // slice records
+	uint32_t* slice_off;     // [max_slices] word offset of each slice record
+	uint8_t* slice_flags;    // [max_slices] bit0 currentlyCorrect, bit1 falseFromCorrect
+	GaTraceStep* trace;      // [trace_cap] staging for the traceback of the current job
+};
+
+GA_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
+
+// ---- graph access (wave-uniform) -------------------------------------------------------------
+GA_FN uint32_t g_len(const GaDevGraph& g, uint32_t n) { return (uint32_t)(g.node_start[n + 1] - g.node_start[n]); }
+GA_FN int g_base(const GaDevGraph& g, uint64_t col) { return (int)((g.seq2[col >> 4] >> ((col & 15) * 2)) & 3); }
+
+// slot of `key` in list[0..count) or -1: 64 entries per step, one ballot
+GA_FN int find_slot(const uint32_t* list, int count, uint32_t key)
+{
+	for (int base = 0; base < count; base += LANES)
+	{
+		VI x = load_lanes(list + base, count - base, -1);
+		uint64_t m = ballot(x == (int)key);
+		if (m) return base + ctz64(m);
+	}
+	return -1;
+}
+
+// ---- std::unordered_map<size_t,..> iteration order after inserting keys[0..n) one by one ----------
+// (NodeSlice.h:728-738 builds the frozen slice's map exactly so; GraphAligner.h:1117 iterates it).
+// libstdc++: identity hash, bucket = key % B, B grows 13,29,59,127,257 when size would exceed it;
+// a node entering an empty bucket becomes the list head, otherwise it goes to the front of its
+// bucket's run; a rehash re-inserts the nodes in their current iteration order.
+template <int MAXN> GA_FN void hash_insert(WaveState<MAXN>& ws, const uint32_t* keys, int i, int B, int& head)
+{
+	int b = (int)(keys[i] % (uint32_t)B);
+	int before = ws.h_before[b];
+	if (before != -1)
+	{
+		if (before == -2) { ws.h_next[i] = (int16_t)head; head = i; }
+		else { ws.h_next[i] = ws.h_next[before]; ws.h_next[before] = (int16_t)i; }
+	}
+	else
+	{
+		ws.h_next[i] = (int16_t)head;
+		if (head != -1) ws.h_before[keys[head] % (uint32_t)B] = (int16_t)i;
+		head = i;
+		ws.h_before[b] = -2;
+	}
+}
+
+template <int MAXN> GA_FN void hash_order(WaveState<MAXN>& ws, const uint32_t* keys, int n)
+{
+	int B = 13, head = -1;
+	for (int b = 0; b < B; b++) ws.h_before[b] = -1;
+	for (int i = 0; i < n; i++)
+	{
+		int grown = i == 13 ? 29 : i == 29 ? 59 : i == 59 ? 127 : i == 127 ? 257 : 0;
+		if (grown)
+		{
+			int k = 0;
+			for (int p = head; p >= 0; p = ws.h_next[p]) ws.h_order[k++] = (int16_t)p;
+			B = grown;
+			head = -1;
+			for (int b = 0; b < B; b++) ws.h_before[b] = -1;
+			for (int q = 0; q < k; q++) hash_insert(ws, keys, ws.h_order[q], B, head);
+		}
+		hash_insert(ws, keys, i, B, head);
+	}
+	int k = 0;
+	for (int p = head; p >= 0; p = ws.h_next[p]) ws.h_order[k++] = (int16_t)p;
+}
+
+// ---- std::priority_queue<.., std::greater<>> over (node, priority), libstdc++ heap algorithms -----
+// (GraphAligner.h:1115; the pop order among equal priorities decides DPSlice::nodes order)
+template <int MAXN> GA_FN void heap_sift_up(WaveState<MAXN>& ws, int hole, int top, uint32_t node, int prio)
+{
+	int parent = (hole - 1) / 2;
+	while (hole > top && ws.heap_prio[parent] > prio)
+	{
+		ws.heap_prio[hole] = ws.heap_prio[parent];
+		ws.heap_node[hole] = ws.heap_node[parent];
+		hole = parent;
+		parent = (hole - 1) / 2;
+	}
+	ws.heap_prio[hole] = prio;
+	ws.heap_node[hole] = node;
+}
+template <int MAXN> GA_FN bool heap_push(WaveState<MAXN>& ws, int& size, uint32_t node, int prio)
+{
+	if (size >= Limits<MAXN>::kHeap) return false;
+	size++;
+	heap_sift_up(ws, size - 1, 0, node, prio);
+	return true;
+}
+template <int MAXN> GA_FN void heap_pop(WaveState<MAXN>& ws, int& size)
+{
+	// std::pop_heap then pop_back: the last element is re-inserted from the root (__adjust_heap)
+	int len = size - 1;
+	uint32_t node = ws.heap_node[len];
+	int prio = ws.heap_prio[len];
+	size = len;
+	if (len == 0) return;
+	int hole = 0, child = 0;
+	while (child < (len - 1) / 2)
+	{
+		child = 2 * (child + 1);
+		if (ws.heap_prio[child] > ws.heap_prio[child - 1]) child--;
+		ws.heap_prio[hole] = ws.heap_prio[child];
+		ws.heap_node[hole] = ws.heap_node[child];
+		hole = child;
+	}
+	if ((len & 1) == 0 && child == (len - 2) / 2)
+	{
+		child = 2 * (child + 1);
+		ws.heap_prio[hole] = ws.heap_prio[child - 1];
+		ws.heap_node[hole] = ws.heap_node[child - 1];
+		hole = child - 1;
+	}
+	heap_sift_up(ws, hole, 0, node, prio);
+}
+
+// ---- band selection at node granularity (GraphAligner.h:1110-1159) ---------------------------------
+template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>& ws, int pn, int prevMin, int bandwidth, int& cn, uint32_t& totalCols)
+{
+	const int expand = bandwidth + W;
+	cn = 0;
+	totalCols = 0;
+	int heapSize = 0;
+	hash_order(ws, ws.pn_node, pn);
+	auto add = [&](uint32_t node, int prevSlot) -> bool {
+		if (cn >= MAXN) return false;
+		uint32_t len = g_len(g, node);
+		ws.cn_node[cn] = node;
+		ws.cn_prev[cn] = (int16_t)prevSlot;
+		ws.cn_len[cn] = len;
+		ws.cn_colBase[cn] = totalCols;
+		totalCols += len;
+		cn++;
+		return true;
+	};
+	for (int k = 0; k < pn; k++)
+	{
+		int s = ws.h_order[k];
+		if (ws.pn_min[s] > prevMin + bandwidth) continue;
+		uint32_t node = ws.pn_node[s];
+		if (!add(node, s)) return GA_CAP_NODES;
+		if (totalCols >= kCutoff) return GA_UNSUPPORTED_BAND;
+		int endScore = ws.pn_lastEnd[s];
+		if (endScore > prevMin + expand) continue;
+		for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
+			if (!heap_push(ws, heapSize, g.out_nbr[e], endScore - prevMin + 1)) return GA_CAP_HEAP;
+	}
+	if (cn == 0) return GA_ASSERTION;                                   // assert(distances.size() > 0) (:1138)
+	while (heapSize > 0)
+	{
+		uint32_t node = ws.heap_node[0];
+		int prio = ws.heap_prio[0];
+		if (prio > expand) break;
+		heap_pop(ws, heapSize);
+		if (find_slot(ws.cn_node, cn, node) >= 0) continue;             // already at a distance <= prio
+		if (!add(node, find_slot(ws.pn_node, pn, node))) return GA_CAP_NODES;
+		if (totalCols >= kCutoff) return GA_UNSUPPORTED_BAND;
+		int len = (int)ws.cn_len[cn - 1];
+		for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
+			if (!heap_push(ws, heapSize, g.out_nbr[e], prio + len)) return GA_CAP_HEAP;
+	}
+	return GA_OK;
+}
+
+// ---- processing order: reverse Tarjan emission order over the band subgraph (:1836-1901, :2360) ----
+// On a DAG every node is its own component and is emitted when its DFS finishes; an edge to a
+// node still on the DFS stack means a cycle, which this kernel does not handle.
+template <int MAXN> GA_FN int processing_order(const GaDevGraph& g, WaveState<MAXN>& ws, int cn)
+{
+	for (int i = 0; i < cn; i++) ws.color[i] = 0;
+	int emitted = 0;
+	for (int root = 0; root < cn; root++)
+	{
+		if (ws.color[root] != 0) continue;
+		int sp = 0;
+		ws.color[root] = 1;
+		ws.st_slot[0] = (int16_t)root;
+		ws.st_cur[0] = g.out_off[ws.cn_node[root]];
+		sp = 1;
+		while (sp > 0)
+		{
+			int v = ws.st_slot[sp - 1];
+			uint32_t cur = ws.st_cur[sp - 1];
+			uint32_t end = g.out_off[ws.cn_node[v] + 1];
+			if (cur < end)
+			{
+				int x = find_slot(ws.cn_node, cn, g.out_nbr[cur]);
+				if (x < 0 || ws.color[x] == 2) { ws.st_cur[sp - 1] = cur + 1; continue; }
+				if (ws.color[x] == 1) return GA_UNSUPPORTED_CYCLE;
+				ws.color[x] = 1;
+				ws.st_slot[sp] = (int16_t)x;
+				ws.st_cur[sp] = g.out_off[ws.cn_node[x]];
+				sp++;
+				continue;
+			}
+			ws.color[v] = 2;
+			ws.post[emitted++] = (int16_t)v;
+			sp--;
+			if (sp > 0) ws.st_cur[sp - 1] += 1;
+		}
+	}
+	return GA_OK;
+}
+
+// ---- slice record layout inside the slot arena ---------------------------------------------------------
+struct SliceRec
+{
+	uint32_t* hdr;       // nNodes, nCols, minScore, minSlot, minOffset, reserved
+	uint32_t* nodes;     // [nNodes]
+	uint32_t* colBase;   // [nNodes]
+	uint64_t* vp;        // [nCols]
+	uint64_t* vn;        // [nCols]
+	int32_t* before;     // [nCols]
+};
+GA_FN uint64_t slice_words(uint32_t nNodes, uint32_t nCols)
+{
+	uint64_t w = kSliceHdrWords + 2ull * nNodes;
+	w += w & 1;                               // 8-byte alignment for the 64-bit planes
+	return w + 5ull * nCols + (nCols & 1);
+}
+GA_FN SliceRec slice_at(uint32_t* arena, uint64_t off, uint32_t nNodes, uint32_t nCols)
+{
+	SliceRec r;
+	r.hdr = arena + off;
+	r.nodes = r.hdr + kSliceHdrWords;
+	r.colBase = r.nodes + nNodes;
+	uint64_t w = kSliceHdrWords + 2ull * nNodes;
+	w += w & 1;
+	r.vp = (uint64_t*)(arena + off + w);
+	r.vn = r.vp + nCols;
+	r.before = (int32_t*)(r.vn + nCols);
+	return r;
+}
+
+// ---- one column -> stored words -------------------------------------------------------------------
+struct ColumnSink
+{
+	VU accVp, accVn;
+	VI accBefore, accEnd;
+	int fill;             // columns waiting in the accumulators
+	uint32_t flushed;     // columns of the slice already written
+};
+
+template <int MAXN>
+GA_FN void flush_columns(ColumnSink& sink, const SliceRec& rec, uint32_t* endCur)
+{
+	if (sink.fill == 0) return;
+	store_lanes(rec.vp + sink.flushed, sink.fill, sink.accVp);
+	store_lanes(rec.vn + sink.flushed, sink.fill, sink.accVn);
+	store_lanes(rec.before + sink.flushed, sink.fill, sink.accBefore);
+	store_lanes(endCur + sink.flushed, sink.fill, sink.accEnd);
+	sink.flushed += sink.fill;
+	sink.fill = 0;
+}
+
+// ---- fill one slice: every band node in processing order (GraphAligner.h:2331-2451, 1457-1573) --------
+// returns status; outputs slice min and the LAST column (in processing order) that attains it
+template <int MAXN>
+GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const uint8_t* rows, uint32_t nRows,
+                     uint32_t j, int pn, int cn, int& sliceMin, int& minSlot, uint32_t& minOffset)
+{
+	(void)pn;
+	const VI lane = lane_iota();
+	const VU lowMask = low_mask_through_lane();
+	const VI rowCode = load_lanes(rows + j, W, 0);
+	if (ballot((rowCode & GA_ROW_INVALID) != 0)) return GA_ASSERTION;          // characterMatch default branch (:2104-2106)
+	const int rawAbove = j > 0 ? (rows[j - 1] >> 4) & 7 : 7;                     // read char of row j-1, exact-compare code
+	sliceMin = INF;
+	minSlot = -1;
+	minOffset = 0;
+	ColumnSink sink;
+	sink.accVp = VU(0); sink.accVn = VU(0); sink.accBefore = VI(0); sink.accEnd = VI(0);
+	sink.fill = 0; sink.flushed = 0;
+
+	for (int oi = cn - 1; oi >= 0; oi--)
+	{
+		const int s = ws.post[oi];
+		const uint32_t node = ws.cn_node[s];
+		const uint32_t len = ws.cn_len[s];
+		const uint64_t firstCol = g.node_start[node];
+		const int ps = ws.cn_prev[s];
+		const bool inPrev = ps >= 0;
+		const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
+		// columns of one node are written contiguously at cn_colBase; flush what belongs elsewhere
+		if (sink.fill && sink.flushed + sink.fill != ws.cn_colBase[s]) flush_columns<MAXN>(sink, rec, slot.end_cur);
+		if (sink.fill == 0) sink.flushed = ws.cn_colBase[s];
+
+		// --- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ---
+		int zero0 = inPrev ? (int)(pend[0] >> 2) : INF;
+		bool hasIn = false;
+		for (uint32_t e = g.in_off[node]; e < g.in_off[node + 1]; e++)
+		{
+			uint32_t m = g.in_nbr[e];
+			int cs = find_slot(ws.cn_node, cn, m);
+			int pm = find_slot(ws.pn_node, pn, m);
+			if (cs < 0 && pm < 0) continue;
+			hasIn = true;
+			if (cs >= 0) zero0 = zero0 < ws.cn_lastBefore[cs] + 1 ? zero0 : ws.cn_lastBefore[cs] + 1;
+			if (pm >= 0) zero0 = zero0 < ws.pn_lastEnd[pm] + 1 ? zero0 : ws.pn_lastEnd[pm] + 1;
+		}
+		int base = g_base(g, firstCol);
+		VI eqLane = (rowCode >> base) & 1;
+		bool aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);       // "previousEq": raw char ==, not characterMatch (:1503)
+		int pend0 = inPrev ? (int)(pend[0] >> 2) : INF;
+		bool exists0 = inPrev && pend0 == zero0;                                 // scoreBeforeExists from :1989 (scoreEndExists is always true here)
+		VI S;
+		int before;
+		bool exists;
+		if (!hasIn)
+		{
+			// source node (:1475-1499)
+			if (j == 0 && inPrev)
+			{
+				int firstMis = 1 - read_lane(eqLane, 0);
+				S = lane + (pend0 + firstMis);
+				before = pend0;
+				exists = true;
+			}
+			else if (inPrev)
+			{
+				S = lane + (pend0 + 1);
+				before = pend0;
+				exists = true;
+			}
+			else
+			{
+				S = lane + (int)(nRows + 1);
+				before = (int)(nRows + 1);
+				exists = false;
+			}
+		}
+		else
+		{
+			// node start: cell-wise min over the in-neighbours' last columns advanced one step (:1270-1315)
+			VI H = VI(INF);
+			int calc = INF;
+			for (uint32_t e = g.in_off[node]; e < g.in_off[node + 1]; e++)
+			{
+				uint32_t m = g.in_nbr[e];
+				int cs = find_slot(ws.cn_node, cn, m);
+				int pm = find_slot(ws.pn_node, pn, m);
+				if (cs < 0 && pm < 0) continue;
+				VI left, eq;
+				int leftBefore;
+				bool leftExists;
+				if (cs >= 0)
+				{
+					leftBefore = ws.cn_lastBefore[cs];
+					left = vpopc(ws.cn_lastVP[cs] & lowMask) - vpopc(ws.cn_lastVN[cs] & lowMask) + leftBefore;
+					leftExists = ws.cn_lastExists[cs] != 0;
+					eq = eqLane;
+				}
+				else
+				{
+					// neighbour only in the previous band: vertical source column, only row j may match (:1294-1301)
+					leftBefore = ws.pn_lastEnd[pm];
+					left = lane + (leftBefore + 1);
+					leftExists = true;
+					eq = select(lane == 0, eqLane, VI(0));
+				}
+				if (!(leftExists && pm >= 0)) eq = select(lane == 0, VI(0), eq);      // Eq bit 0 masked (:1358,1360)
+				VI diag = shr1(left, leftBefore);
+				H = vmin(H, vmin(left + 1, diag + 1 - eq));
+				int viaLeft = leftBefore + 1;
+				if (exists0 && pm >= 0)
+				{
+					int viaDiag = ws.pn_lastEnd2[pm] + (aboveEq ? 0 : 1);
+					viaLeft = viaLeft < viaDiag ? viaLeft : viaDiag;
+				}
+				calc = calc < viaLeft ? calc : viaLeft;
+			}
+			bool reenter = inPrev && calc > pend0;                               // vertical re-entry (:1504-1509)
+			before = reenter ? pend0 : calc;
+			exists = reenter ? true : exists0;
+			VI pm = prefix_min(H - lane);
+			S = vmin(pm + lane, lane + (before + 1));
+		}
+
+		int nodeMin = INF;
+		int zero = zero0;
+		for (uint32_t w = 0;; w++)
+		{
+			// ---- emit column w ----
+			VI up = shr1(S, before);
+			VI delta = S - up;
+			uint64_t vp = ballot(delta == 1);
+			uint64_t vn = ballot(delta == -1);
+			int end = read_lane(S, 63);
+			int end2 = read_lane(S, 62);
+			int packed = (end << 2) | (end - end2 == 1 ? 1 : 0) | (end - end2 == -1 ? 2 : 0);
+			VB here = lane == sink.fill;
+			sink.accVp = select(here, VU(vp), sink.accVp);
+			sink.accVn = select(here, VU(vn), sink.accVn);
+			sink.accBefore = select(here, VI(before), sink.accBefore);
+			sink.accEnd = select(here, VI(packed), sink.accEnd);
+			sink.fill++;
+			if (sink.fill == LANES) flush_columns<MAXN>(sink, rec, slot.end_cur);
+			nodeMin = end < nodeMin ? end : nodeMin;
+			if (end <= sliceMin) { sliceMin = end; minSlot = s; minOffset = w; }   // last minimum in processing order (:1551-1559, 2410-2418)
+			if (w + 1 == len)
+			{
+				if (before != zero) return GA_ASSERTION;                         // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
+				if (GA_LANE0)
+				{
+					ws.cn_lastVP[s] = vp; ws.cn_lastVN[s] = vn; ws.cn_lastBefore[s] = before; ws.cn_lastExists[s] = exists ? 1 : 0;
+					ws.cn_min[s] = nodeMin; ws.cn_lastEnd[s] = end; ws.cn_lastEnd2[s] = end2;
+				}
+				break;
+			}
+			// ---- column w+1 from column w (calculateNode inner loop :1533-1546, getNextSlice :1349-1427) ----
+			base = g_base(g, firstCol + w + 1);
+			eqLane = (rowCode >> base) & 1;
+			aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);
+			int pendW = inPrev ? (int)(pend[w + 1] >> 2) : INF;
+			zero = zero + 1 < pendW ? zero + 1 : pendW;                         // row j-1 chain (:1939-1944)
+			bool existsW = inPrev && pendW == zero;
+			VI eq = exists ? eqLane : select(lane == 0, VI(0), eqLane);
+			VI diag = shr1(S, before);
+			VI H = vmin(S + 1, diag + 1 - eq);
+			int calc = before + 1;
+			if (existsW)
+			{
+				uint32_t pl = pend[w];
+				int aboveLeft2 = (int)(pl >> 2) - (int)(pl & 1) + (int)((pl >> 1) & 1);
+				int viaDiag = aboveLeft2 + (aboveEq ? 0 : 1);
+				calc = calc < viaDiag ? calc : viaDiag;
+			}
+			bool reenter = inPrev && calc > pendW;                               // vertical re-entry (:1541-1546)
+			before = reenter ? pendW : calc;
+			exists = reenter ? true : existsW;
+			VI pmn = prefix_min(H - lane);
+			S = vmin(pmn + lane, lane + (before + 1));
+		}
+	}
+	flush_columns<MAXN>(sink, rec, slot.end_cur);
+	return GA_OK;
+}
+
+// ---- cell value from the stored words (WordSlice.h:223-229; getValueOrMax GraphAligner.h:2008-2017) ------
+struct SliceView { const uint32_t* arena; const uint32_t* slice_off; };
+
+GA_FN int stored_value(const SliceRec& r, uint32_t nNodes, uint32_t node, uint32_t offset, int rowInSlice, int big)
+{
+	int slot = find_slot(r.nodes, (int)nNodes, node);
+	if (slot < 0) return big;
+	uint32_t idx = r.colBase[slot] + offset;
+	uint64_t vp = r.vp[idx], vn = r.vn[idx];
+	uint64_t mask = rowInSlice < 63 ? ~(~0ull << (rowInSlice + 1)) : ~0ull;
+	return r.before[idx] + __builtin_popcountll(vp & mask) - __builtin_popcountll(vn & mask);
+}
+
+// ---- the whole job --------------------------------------------------------------------------------------------
+template <int MAXN>
+GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, uint32_t jobIndex)
+{
+	const GaDevGraph& g = L.graph;
+	const GaJob job = L.jobs[jobIndex];
+	const GaHmmTables& hmm = *L.hmm;
+	const uint8_t* rows = L.rows + job.rows_off;
+	Slot slot = slotIn;
+	GaJobOut out;
+	out.status = GA_OK; out.score = 0x7fffffff; out.n_valid = 0; out.n_run = 0; out.trace_len = 0; out.max_band_nodes = 0; out.n_columns = 0; out.trace_off = 0;
+	const uint32_t numSlices = job.n_rows / W;
+	int status = GA_OK;
+
+	// ---- initial slice: the whole seed node at score 0 (GraphAligner.h:2945-2960) ----
+	int pn = 1;
+	uint32_t seedLen = g_len(g, job.seed_node);
+	if (seedLen > L.cap_cols) status = GA_CAP_COLS;
+	if (status == GA_OK)
+	{
+		if (GA_LANE0)
+		{
+			ws.pn_node[0] = job.seed_node; ws.pn_min[0] = 0; ws.pn_lastEnd[0] = 0; ws.pn_lastEnd2[0] = 0; ws.pn_colBase[0] = 0;
+		}
+		for (uint32_t c = 0; c < seedLen; c += LANES) store_lanes(slot.end_prev + c, (int)(seedLen - c), VI(0));
+	}
+	wave_sync();
+	int prevMin = 0;
+	double logCorrect = hmm.init_correct, logWrong = hmm.init_wrong;
+	uint64_t arenaTop = 0;
+	uint32_t nPushed = 0;          // bandwidthPerSlice.size()
+	uint32_t nRun = 0;
+	const bool rampPossible = L.ramp_bw > L.initial_bw;
+
+	for (uint32_t slice = 0; slice < numSlices && status == GA_OK; slice++)
+	{
+		// slice 0 always runs at the ramp width because rampUntil(0) >= slice(0) (:2603,2612)
+		const int bandwidth = slice == 0 ? L.ramp_bw : L.initial_bw;
+		int cn = 0;
+		uint32_t totalCols = 0;
+		status = project_band(g, ws, pn, prevMin, bandwidth, cn, totalCols);
+		if (status != GA_OK) break;
+		if (totalCols > L.cap_cols) { status = GA_CAP_COLS; break; }
+		wave_sync();
+		status = processing_order(g, ws, cn);
+		if (status != GA_OK) break;
+		uint64_t need = slice_words((uint32_t)cn, totalCols);
+		if (arenaTop + need > L.arena_words) { status = GA_CAP_ARENA; break; }
+		SliceRec rec = slice_at(slot.arena, arenaTop, (uint32_t)cn, totalCols);
+		for (int c = 0; c < cn; c += LANES)
+		{
+			store_lanes(rec.nodes + c, cn - c, load_lanes(ws.cn_node + c, cn - c, 0));
+			store_lanes(rec.colBase + c, cn - c, load_lanes(ws.cn_colBase + c, cn - c, 0));
+		}
+		wave_sync();
+		int sliceMin, minSlot;
+		uint32_t minOffset;
+		status = fill_slice(g, ws, slot, rec, rows, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
+		if (status != GA_OK) break;
+		if (sliceMin < prevMin) { status = GA_ASSERTION; break; }                 // :2469
+		if (GA_LANE0)
+		{
+			rec.hdr[0] = (uint32_t)cn; rec.hdr[1] = totalCols; rec.hdr[2] = (uint32_t)sliceMin; rec.hdr[3] = (uint32_t)minSlot; rec.hdr[4] = minOffset; rec.hdr[5] = 0;
+			slot.slice_off[slice] = (uint32_t)arenaTop;
+		}
+		nRun++;
+		out.n_columns += totalCols;
+		out.max_band_nodes = out.max_band_nodes > (uint32_t)cn ? out.max_band_nodes : (uint32_t)cn;
+		// ---- HMM step (AlignmentCorrectnessEstimation.cpp:71-89): additions and comparisons only ----
+		int mism = sliceMin - prevMin;
+		if (mism > 64) { status = GA_ASSERTION; break; }
+		double cc = logCorrect + hmm.c2c, fc = logWrong + hmm.f2c, cf = logCorrect + hmm.c2f, ff = logWrong + hmm.f2f;
+		bool correctFromCorrect = cc >= fc;
+		bool falseFromCorrect = cf >= ff;
+		logCorrect = (cc > fc ? cc : fc) + hmm.correct_mult[mism];
+		logWrong = (cf > ff ? cf : ff) + hmm.wrong_mult[mism];
+		bool currentlyCorrect = logCorrect > logWrong;
+		if (!correctFromCorrect) break;                                          // :2640-2647 (this slice is not kept)
+		if (!currentlyCorrect && slice > 0 && rampPossible) { status = GA_UNSUPPORTED_RAMP; break; }   // :2648
+		if (GA_LANE0) slot.slice_flags[slice] = (uint8_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0));
+		nPushed++;
+		arenaTop += need;
+		// ---- current band becomes the previous one ----
+		wave_sync();
+		for (int c = 0; c < cn; c += LANES)
+		{
+			int k = cn - c;
+			store_lanes(ws.pn_node + c, k, load_lanes(ws.cn_node + c, k, 0));
+			store_lanes(ws.pn_min + c, k, load_lanes(ws.cn_min + c, k, 0));
+			store_lanes(ws.pn_lastEnd + c, k, load_lanes(ws.cn_lastEnd + c, k, 0));
+			store_lanes(ws.pn_lastEnd2 + c, k, load_lanes(ws.cn_lastEnd2 + c, k, 0));
+			store_lanes(ws.pn_colBase + c, k, load_lanes(ws.cn_colBase + c, k, 0));
+		}
+		pn = cn;
+		prevMin = sliceMin;
+		uint32_t* t = slot.end_prev; slot.end_prev = slot.end_cur; slot.end_cur = t;
+		wave_sync();
+	}
+	out.n_run = nRun;
+
+	// ---- drop the wrongly aligned tail (removeWronglyAlignedEnd, :2554-2569) ----
+	uint32_t kept = nPushed;
+	if (status == GA_OK && kept > 0)
+	{
+		wave_sync();
+		bool ok = slot.slice_flags[kept - 1] & 1;
+		while (!ok)
+		{
+			kept--;
+			if (kept == 0) break;
+			ok = (slot.slice_flags[kept - 1] & 2) != 0;
+		}
+	}
+	out.n_valid = status == GA_OK ? kept : 0;
+
+	// ---- traceback (getTraceFromTable :894-957 with pickBacktracePredecessor :493-591) ----
+	if (status == GA_OK && kept > 0)
+	{
+		if (numSlices < 4) status = GA_ASSERTION;                                // assert(slice.samplingFrequency > 1) (:906)
+	}
+	if (status == GA_OK && kept > 0)
+	{
+		GaTraceStep* tr = slot.trace;
+		const int big = (int)job.n_rows;                                         // getValueOrMax default = sequence.size()
+		uint32_t sIdx = kept - 1;
+		uint32_t off = slot.slice_off[sIdx];
+		uint32_t nN = slot.arena[off], nC = slot.arena[off + 1];
+		SliceRec cur = slice_at(slot.arena, off, nN, nC);
+		out.score = (int32_t)cur.hdr[2];
+		uint32_t node = cur.nodes[cur.hdr[3]];
+		uint32_t offset = cur.hdr[4];
+		uint32_t row = sIdx * W + (W - 1);
+		uint32_t len = 0;
+		bool havePrev = false;
+		SliceRec prv = cur;
+		uint32_t pN = 0;
+		auto loadPrev = [&]() {
+			if (sIdx == 0) { havePrev = false; return; }
+			uint32_t o = slot.slice_off[sIdx - 1];
+			pN = slot.arena[o];
+			prv = slice_at(slot.arena, o, pN, slot.arena[o + 1]);
+			havePrev = true;
+		};
+		loadPrev();
+		auto valuePrevLastRow = [&](uint32_t n, uint32_t o2) -> int {
+			// row 63 of the slice before; before slice 0 that is the all-zero seed slice
+			if (sIdx == 0) return n == job.seed_node ? 0 : big;
+			return stored_value(prv, pN, n, o2, W - 1, big);
+		};
+		while (true)
+		{
+			if (len >= L.trace_cap) { status = GA_CAP_TRACE; break; }
+			if (GA_LANE0) { tr[len].node = node; tr[len].offset = offset; tr[len].row = row; }
+			len++;
+			if (row == 0xffffffffu) break;                                       // reached the row before the first one
+			const int r = (int)(row - sIdx * W);
+			const int here = stored_value(cur, nN, node, offset, r, big);
+			if (row == 0 && node == job.seed_node && (here == 0 || here == 1)) { row = 0xffffffffu; continue; }   // free start (:500)
+			const int rowCode = rows[row];
+			const int base = g_base(g, g.node_start[node] + offset);
+			const bool match = (rowCode >> base) & 1;
+			bool moved = false;
+			auto tryFrom = [&](uint32_t un, uint32_t uo) -> int {
+				int horizontal = stored_value(cur, nN, un, uo, r, big);
+				if (horizontal < here - 1) return -1;
+				if (horizontal == here - 1) { node = un; offset = uo; return 1; }
+				int diagonal = r == 0 ? valuePrevLastRow(un, uo) : stored_value(cur, nN, un, uo, r - 1, big);
+				if (match)
+				{
+					if (diagonal < here) return -1;
+					if (diagonal == here) { node = un; offset = uo; row = row - 1; return 2; }
+				}
+				else
+				{
+					if (diagonal < here - 1) return -1;
+					if (diagonal == here - 1) { node = un; offset = uo; row = row - 1; return 2; }
+				}
+				return 0;
+			};
+			int res = 0;
+			const uint32_t curNode = node, curOffset = offset;
+			if (curOffset == 0)
+			{
+				for (uint32_t e = g.in_off[curNode]; e < g.in_off[curNode + 1] && res == 0; e++)
+				{
+					uint32_t m = g.in_nbr[e];
+					res = tryFrom(m, g_len(g, m) - 1);
+				}
+			}
+			else res = tryFrom(curNode, curOffset - 1);
+			if (res < 0) { status = GA_ASSERTION; break; }
+			if (res == 0)
+			{
+				int up = r == 0 ? valuePrevLastRow(curNode, curOffset) : stored_value(cur, nN, curNode, curOffset, r - 1, big);
+				if (up != here - 1) { status = GA_ASSERTION; break; }            // assert(false) (:588)
+				row = row - 1;
+				res = 2;
+			}
+			moved = res == 2;
+			if (moved && r == 0 && row != 0xffffffffu)
+			{
+				// stepped into the slice above
+				sIdx--;
+				cur = prv; nN = pN;
+				loadPrev();
+			}
+		}
+		// hand the steps over: claim exactly `len` entries of the pool and copy them, 64 at a time
+		if (status == GA_OK)
+		{
+			wave_sync();
+			uint64_t at = wave_atomic_add(L.trace_top, (uint64_t)len);
+			if (at + len > L.trace_pool_cap) status = GA_CAP_TRACE;
+			else
+			{
+				uint32_t* dst = (uint32_t*)(L.traces + at);
+				const uint32_t* src = (const uint32_t*)tr;
+				for (uint32_t c = 0; c < 3 * len; c += LANES) store_lanes(dst + c, (int)(3 * len - c), load_lanes(src + c, (int)(3 * len - c), 0));
+				out.trace_off = at;
+				out.trace_len = len;
+			}
+		}
+	}
+	out.status = status;
+	if (GA_LANE0) L.outs[jobIndex] = out;
+}
+
+}  // namespace gak

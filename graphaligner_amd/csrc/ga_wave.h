@@ -1,0 +1,143 @@
+// ga_wave.h -- the handful of wave64 primitives the alignment program is written in.
+//
+// Two back ends behind one vocabulary:
+//   * device (default, hipcc --offload-arch=gfx950): a per-lane value IS a register; the
+//     cross-lane operations are DPP moves (wave_shr / row_shr / row_bcast), v_readlane and
+//     ballots.  64 lanes = the 64 read rows of one slice.
+//   * GA_EMULATE (tests only, plain g++): a per-lane value is an array of 64 and every
+//     primitive is a loop.  This exists so the exact device program can be checked against
+//     the oracle in the CPU-only container; it is never part of the product library.
+#pragma once
+#include <stdint.h>
+
+namespace gaw {
+
+constexpr int LANES = 64;
+constexpr int INF = 0x3fffffff;
+
+#ifdef GA_EMULATE
+// =========================================================================================
+// host emulation
+// =========================================================================================
+#define GA_FN inline
+#define GA_LANE0 true
+
+struct VB { bool v[LANES]; };
+struct VI
+{
+	int v[LANES];
+	VI() {}
+	VI(int s) { for (int i = 0; i < LANES; i++) v[i] = s; }
+};
+struct VU
+{
+	uint64_t v[LANES];
+	VU() {}
+	VU(uint64_t s) { for (int i = 0; i < LANES; i++) v[i] = s; }
+};
+
+#define GAW_BIN(OP) \
+	inline VI operator OP(const VI& a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
+	inline VI operator OP(const VI& a, int b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] OP b; return r; } \
+	inline VI operator OP(int a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a OP b.v[i]; return r; }
+GAW_BIN(+) GAW_BIN(-) GAW_BIN(&) GAW_BIN(|) GAW_BIN(>>) GAW_BIN(<<)
+#undef GAW_BIN
+#define GAW_CMP(OP) \
+	inline VB operator OP(const VI& a, const VI& b) { VB r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
+	inline VB operator OP(const VI& a, int b) { VB r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] OP b; return r; }
+GAW_CMP(==) GAW_CMP(<) GAW_CMP(>) GAW_CMP(!=)
+#undef GAW_CMP
+inline VB operator&&(const VB& a, const VB& b) { VB r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
+inline VB operator&&(const VB& a, bool b) { VB r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] && b; return r; }
+inline VU operator&(uint64_t a, const VU& b) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = a & b.v[i]; return r; }
+
+inline VI lane_iota() { VI r; for (int i = 0; i < LANES; i++) r.v[i] = i; return r; }
+inline VI vmin(const VI& a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VI vmin(const VI& a, int b) { return vmin(a, VI(b)); }
+inline VI select(const VB& c, const VI& a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VU select(const VB& c, const VU& a, const VU& b) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VI vpopc(const VU& a) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = __builtin_popcountll(a.v[i]); return r; }
+// bits 0..lane of a 64-bit word
+inline VU low_mask_through_lane() { VU r; for (int i = 0; i < LANES; i++) r.v[i] = i == 63 ? ~0ull : ((2ull << i) - 1); return r; }
+
+// lane i receives lane i-1; lane 0 receives `fill`
+inline VI shr1(const VI& x, int fill) { VI r; r.v[0] = fill; for (int i = 1; i < LANES; i++) r.v[i] = x.v[i - 1]; return r; }
+// inclusive prefix minimum over lanes 0..i
+inline VI prefix_min(const VI& x) { VI r; int m = INF; for (int i = 0; i < LANES; i++) { m = x.v[i] < m ? x.v[i] : m; r.v[i] = m; } return r; }
+inline uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < LANES; i++) if (c.v[i]) m |= 1ull << i; return m; }
+inline int read_lane(const VI& x, int lane) { return x.v[lane]; }
+inline uint64_t read_lane(const VU& x, int lane) { return x.v[lane]; }
+
+// lane i (< count) loads / stores element i; other lanes get `fill` / do nothing
+template <typename T> inline VI load_lanes(const T* p, int count, int fill) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = i < count ? (int)p[i] : fill; return r; }
+template <typename T> inline void store_lanes(T* p, int count, const VI& x) { for (int i = 0; i < LANES && i < count; i++) p[i] = (T)x.v[i]; }
+inline void store_lanes(uint64_t* p, int count, const VU& x) { for (int i = 0; i < LANES && i < count; i++) p[i] = x.v[i]; }
+inline void wave_sync() {}
+// one reservation for the whole wave; every lane sees the old value
+inline uint64_t wave_atomic_add(uint64_t* p, uint64_t v) { uint64_t r = *p; *p += v; return r; }
+inline uint32_t wave_atomic_add(uint32_t* p, uint32_t v) { uint32_t r = *p; *p += v; return r; }
+
+#else
+// =========================================================================================
+// gfx950 device
+// =========================================================================================
+#define GA_FN __device__ __forceinline__
+#define GA_LANE0 (threadIdx.x == 0)
+
+typedef bool VB;
+typedef int VI;
+typedef uint64_t VU;
+
+GA_FN VI lane_iota() { return (int)threadIdx.x; }
+GA_FN VI vmin(VI a, VI b) { return a < b ? a : b; }
+GA_FN VI select(VB c, VI a, VI b) { return c ? a : b; }
+GA_FN VU select(VB c, VU a, VU b) { return c ? a : b; }
+GA_FN VI vpopc(VU a) { return __builtin_popcountll(a); }
+GA_FN VU low_mask_through_lane() { return threadIdx.x == 63 ? ~0ull : ((2ull << threadIdx.x) - 1); }
+
+// v_mov_b32 dpp wave_shr:1 -- lane 0 has no source lane and keeps `fill`
+GA_FN VI shr1(VI x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+// wave64 inclusive scan: row_shr 1,2,4,8 inside each row of 16, then row_bcast:15 into rows
+// 1 and 3, then row_bcast:31 into rows 2 and 3
+GA_FN VI prefix_min(VI v)
+{
+	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x111, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x112, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x114, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x118, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x142, 0xa, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x143, 0xc, 0xf, false));
+	return v;
+}
+GA_FN uint64_t ballot(VB c) { return __ballot(c); }
+GA_FN int read_lane(VI x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+GA_FN uint64_t read_lane(VU x, int lane)
+{
+	uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+	uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
+	return ((uint64_t)hi << 32) | lo;
+}
+template <typename T> GA_FN VI load_lanes(const T* p, int count, int fill) { return (int)threadIdx.x < count ? (int)p[threadIdx.x] : fill; }
+template <typename T> GA_FN void store_lanes(T* p, int count, VI x) { if ((int)threadIdx.x < count) p[threadIdx.x] = (T)x; }
+GA_FN void store_lanes(uint64_t* p, int count, VU x) { if ((int)threadIdx.x < count) p[threadIdx.x] = x; }
+// one wave per workgroup: orders this wave's LDS / global traffic (s_waitcnt + s_barrier)
+GA_FN void wave_sync() { __syncthreads(); }
+// lane 0 performs the device-scope atomic, the old value is broadcast to the wave
+GA_FN uint32_t wave_atomic_add(uint32_t* p, uint32_t v)
+{
+	uint32_t r = 0;
+	if (threadIdx.x == 0) r = atomicAdd(p, v);
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+GA_FN uint64_t wave_atomic_add(uint64_t* p, uint64_t v)
+{
+	unsigned long long r = 0;
+	if (threadIdx.x == 0) r = atomicAdd((unsigned long long*)p, (unsigned long long)v);
+	uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+	uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32));
+	return ((uint64_t)hi << 32) | lo;
+}
+
+#endif
+
+}  // namespace gaw

@@ -198,7 +198,7 @@ def add_errors(seq, sub, ins, dele, rng):
     return np.concatenate(pieces)
 
 
-def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1, both_strands=True, mid_seed=False):
+def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1, both_strands=True, mid_seed=False, min_part=2):
     """returns (reads, seeds): reads are str, seeds are (bigraph node id, read position, reverse).
     The seed names the node holding the read's first base (position 0) or, with mid_seed, the
     node holding the base at the middle of the read (exercises the backward extension)."""
@@ -206,7 +206,11 @@ def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1
     g = graph
     n = len(g.genome)
     reads, seeds = [], []
+    attempts = 0
     while len(reads) < n_reads:
+        attempts += 1
+        if attempts > 50 * n_reads + 1000:
+            raise RuntimeError("simulate_reads: cannot place %d reads of %d bp on this graph" % (n_reads, length))
         start = g._backbone_start(int(rng.integers(0, max(1, n - length - 1200))))
         hap = g.haplotype_window(start, length, rng)
         if len(hap) < length:
@@ -224,13 +228,13 @@ def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1
                 second = g.haplotype_window(anchor, length - half, rng)
                 a = add_errors(first, sub, ins, dele, rng)
                 b = add_errors(second, sub, ins, dele, rng)
-                if len(a) < 200 or len(b) < 200:
+                if len(a) < min_part or len(b) < min_part:
                     continue
                 reads.append(np.concatenate([a, b]).tobytes().decode())
                 seeds.append((int(g.node_at[anchor]), len(a), False))
             else:
                 r = add_errors(hap, sub, ins, dele, rng)
-                if len(r) < 200:
+                if len(r) < min_part:
                     continue
                 reads.append(r.tobytes().decode())
                 seeds.append((int(g.node_at[start]), 0, False))
@@ -240,7 +244,7 @@ def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1
             if anchor >= n - 1:
                 continue
             body = _hap_until(g, start, anchor + 1, rng)     # includes the anchor base
-            if len(body) < 200:
+            if len(body) < min_part:
                 continue
             rc = revcomp_bytes(body)
             if mid_seed:
@@ -249,13 +253,13 @@ def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1
                 right = _hap_until(g, mid_anchor + 1, anchor + 1, rng)
                 a = add_errors(revcomp_bytes(right), sub, ins, dele, rng)
                 b = add_errors(revcomp_bytes(left), sub, ins, dele, rng)
-                if len(a) < 200 or len(b) < 200:
+                if len(a) < min_part or len(b) < min_part:
                     continue
                 reads.append(np.concatenate([a, b]).tobytes().decode())
                 seeds.append((int(g.node_at[mid_anchor]), len(a), True))
             else:
                 r = add_errors(rc, sub, ins, dele, rng)
-                if len(r) < 200:
+                if len(r) < min_part:
                     continue
                 reads.append(r.tobytes().decode())
                 seeds.append((int(g.node_at[anchor]), 0, True))

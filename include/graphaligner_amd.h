@@ -1,0 +1,162 @@
+/* graphaligner_amd.h -- C ABI of the MI355X-native seed-and-extend aligner.
+ *
+ * Drop-in boundary: the two free functions the reference's driver calls per read,
+ *     AlignmentResult AlignOneWay(const AlignmentGraph&, const std::string& seq_id,
+ *                                 const std::string& sequence, int initialBandwidth,
+ *                                 int rampBandwidth, size_t dynamicRowStart,
+ *                                 const std::vector<std::tuple<int,size_t,bool>>& seedHits);
+ * (reference GraphAlignerWrapper.h:53-54, called from Aligner.cpp:128,140), plus the graph
+ * construction calls its loaders make (AlignmentGraph.h:25-28, BigraphToDigraph.cpp:106-189).
+ * A GPU cannot be fed one read per call, so the ABI is batch-first; AlignOneWay is the
+ * one-element case (see INTEGRATION.md for the C++ shim a maintainer would add).
+ *
+ * Plain pointers and sizes only.  No exceptions cross this boundary: every function returns
+ * a ga_status, and per-read failures are reported in ga_read_result.status / .failed
+ * (replacing ThreadReadAssertion::AssertionFailure, GraphAligner.h assert()s, and the
+ * alignmentFailed / INT32_MAX-score convention of GraphAligner.h:636-641).
+ *
+ * The library needs a gfx950 device: ga_graph_upload / ga_batch_run return GA_E_NO_DEVICE
+ * when none is usable.  There is no CPU fallback.
+ */
+#ifndef GRAPHALIGNER_AMD_H
+#define GRAPHALIGNER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ga_status {
+	GA_S_OK = 0,
+	/* per-read outcomes (ga_read_result.status) */
+	GA_S_ASSERTION = 1,         /* the reference's always-on assert() throws for this read (Aligner.cpp:143) */
+	GA_S_UNSUPPORTED_BAND = 2,  /* band >= 200000 bp: reference uses its sparse method (GraphAligner.h:2483); not built */
+	GA_S_BAD_SEED = 3,          /* seed node id unknown: std::out_of_range in the reference (GraphAligner.h:423) */
+	GA_S_CAPACITY = 10,         /* device buffers too small even after the automatic retry */
+	GA_S_UNSUPPORTED_CYCLE = 20,/* band subgraph has a cycle (GraphAligner.h:2362-2397 iterative confirmation); not built */
+	GA_S_UNSUPPORTED_RAMP = 21, /* ramp redo (GraphAligner.h:2648-2719) would be taken; not built */
+	/* call-level errors */
+	GA_E_INVALID = 100,
+	GA_E_NO_DEVICE = 101,
+	GA_E_DEVICE = 102,
+	GA_E_NOT_FINALIZED = 103
+} ga_status;
+
+/* ---- graph: mirrors AlignmentGraph's public build interface (AlignmentGraph.h:25-28) ---------- */
+typedef struct ga_graph ga_graph_t;
+
+ga_graph_t* ga_graph_create(void);                                         /* AlignmentGraph::AlignmentGraph (AlignmentGraph.cpp:12-31) */
+void ga_graph_destroy(ga_graph_t* g);
+/* AlignmentGraph::AddNode (AlignmentGraph.cpp:47-89): digraph id, ACGT sequence; duplicate ids are ignored */
+int ga_graph_add_node(ga_graph_t* g, int64_t digraph_id, const char* seq, size_t len, int reverse_node);
+/* AlignmentGraph::AddEdgeNodeId (AlignmentGraph.cpp:91-106): duplicate edges are ignored */
+int ga_graph_add_edge(ga_graph_t* g, int64_t from_digraph_id, int64_t to_digraph_id);
+/* the loaders' bidirected -> directed conversion (BigraphToDigraph.cpp:27-56, 58-104):
+ * node id -> 2*id (forward) and 2*id+1 (reverse complement); each edge -> two directed edges */
+int ga_graph_add_bigraph_node(ga_graph_t* g, int64_t id, const char* seq, size_t len);
+int ga_graph_add_bigraph_edge(ga_graph_t* g, int64_t from, int from_start, int64_t to, int to_end);
+/* AlignmentGraph::Finalize (AlignmentGraph.cpp:108-154); dbg_overlap = AlignmentGraph::DBGOverlap */
+int ga_graph_finalize(ga_graph_t* g, int dbg_overlap);
+/* DirectedGraph::StreamGFAGraphFromFile (BigraphToDigraph.cpp:137-189) over an in-memory GFA text; finalizes */
+int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len);
+/* copy the flattened graph into the HBM of `device` (replicated per GPU; one process per GPU) */
+int ga_graph_upload(ga_graph_t* g, int device);
+int64_t ga_graph_node_count(const ga_graph_t* g);   /* AlignmentGraph::NodeSize, including the two dummy nodes */
+int64_t ga_graph_bp(const ga_graph_t* g);           /* AlignmentGraph::SizeInBp */
+
+/* ---- reads and seeds ----------------------------------------------------------------------------- */
+typedef struct ga_read {
+	const char* name;        /* seq_id */
+	const char* sequence;
+	size_t length;
+} ga_read_t;
+
+typedef struct ga_seed {     /* std::tuple<int,size_t,bool> seedHits (Aligner.cpp:269) */
+	int64_t node_id;         /* BIGRAPH node id */
+	uint64_t read_pos;       /* query_position */
+	int32_t reverse;
+	int32_t reserved;
+} ga_seed_t;
+
+/* ---- results: flat POD mirror of AlignmentResult (GraphAlignerWrapper.h:10-51) ---------------------- */
+typedef struct ga_mapping {  /* vg::Mapping with its single vg::Edit (GraphAligner.h:782-847) */
+	int64_t node_id;         /* DIGRAPH id, as the engine returns it; the driver halves it (Aligner.cpp:83-91) */
+	int32_t is_reverse;
+	int32_t rank;
+	int64_t offset;          /* Position.offset: set on the first mapping only */
+	int64_t from_length;
+	int64_t to_length;
+	uint64_t edit_seq_off;   /* Edit.sequence = results->edit_bytes[edit_seq_off .. +to_length) */
+} ga_mapping_t;
+
+typedef struct ga_trace_item {   /* AlignmentResult::TraceItem (GraphAlignerWrapper.h:22-31) */
+	int32_t node_id;
+	int32_t reverse;
+	uint64_t offset;
+	uint64_t read_pos;
+	int32_t type;            /* 1 MATCH 2 MISMATCH 3 INSERTION 4 DELETION 5 FORWARDBACKWARDSPLIT */
+	char graph_char;
+	char read_char;
+	char pad[2];
+} ga_trace_item_t;
+
+typedef struct ga_read_result {
+	int32_t status;          /* ga_status, per read */
+	int32_t failed;          /* AlignmentResult::alignmentFailed */
+	int32_t score;           /* vg::Alignment.score; INT32_MAX when failed */
+	int32_t reserved;
+	uint64_t alignment_start, alignment_end, query_position;
+	uint64_t first_mapping, n_mappings;     /* into results->mappings */
+	uint64_t first_trace, n_trace;          /* into results->trace (empty unless requested) */
+	uint64_t column_updates;                /* band columns computed for this read (first pass) */
+} ga_read_result_t;
+
+typedef struct ga_results {
+	size_t n_reads;
+	const ga_read_result_t* reads;
+	size_t n_mappings;
+	const ga_mapping_t* mappings;
+	size_t n_edit_bytes;
+	const char* edit_bytes;
+	size_t n_trace;
+	const ga_trace_item_t* trace;
+} ga_results_t;
+
+/* ---- alignment ----------------------------------------------------------------------------------------- */
+/* reads[i] owns seeds[seed_offsets[i] .. seed_offsets[i+1]).  flags: GA_F_TRACE fills TraceItem lists. */
+#define GA_F_TRACE 1u
+int ga_align_batch(const ga_graph_t* g, const ga_read_t* reads, size_t n_reads, const ga_seed_t* seeds, const size_t* seed_offsets,
+                   int initial_bandwidth, int ramp_bandwidth, uint32_t flags, ga_results_t** out);
+void ga_results_free(ga_results_t* r);
+
+/* staged form of the same call, for callers that keep inputs resident in HBM and for measurement:
+ *   prepare = validate seeds, build extension jobs, upload reads;  run = the device work only;
+ *   collect = download + assemble AlignmentResults. */
+typedef struct ga_batch ga_batch_t;
+int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t n_reads, const ga_seed_t* seeds, const size_t* seed_offsets,
+                     int initial_bandwidth, int ramp_bandwidth, uint32_t flags, ga_batch_t** out);
+int ga_batch_run(ga_batch_t* b);
+int ga_batch_collect(ga_batch_t* b, ga_results_t** out);
+void ga_batch_free(ga_batch_t* b);
+
+typedef struct ga_batch_stats {
+	uint64_t n_jobs;             /* extension jobs (read directions) */
+	uint64_t column_updates;     /* sum over jobs of band columns computed (unit of work) */
+	uint64_t slices;             /* 64-row slices computed */
+	uint64_t jobs_retried;       /* jobs rerun with the wide-band kernel variant */
+	double kernel_ms;            /* HIP-event time of the extension kernel(s) of the last ga_batch_run */
+	double prep_kernel_ms;       /* HIP-event time of the read-coding kernel */
+	uint32_t slots, waves_per_cu;
+	uint64_t scratch_bytes;
+} ga_batch_stats_t;
+int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out);
+
+const char* ga_status_string(int status);
+const char* ga_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,121 @@
+"""Parity cases shared by the GPU tests (real library) and the emulated-device tests (the same
+device program executed on the host, tests/emul).  Every case compares the C ABI's results with
+the CPU oracle on identical seeded inputs, bit for bit."""
+import numpy as np
+
+from graphaligner_amd import binding, synth
+import parity_common as pc
+
+
+def case_wave_primitives_on_hardware(lib_path=None):
+    """the DPP scan / shift the program is built from, checked through a whole alignment that
+    only matches when they behave as the host emulation does"""
+    g = synth.linear_graph(30000, node_len=64, seed=3)
+    reads, seeds = synth.simulate_reads(g, 8, 1200, seed=9)
+    pc.check_parity(g.nodes, g.edges, reads, seeds, 35, lib_path=lib_path, ctx="linear")
+
+
+RANDOM_GRAPHS = [(64, 0, 0, 0), (64, 100, 1000, 0), (32, 40, 300, 3000), (8, 15, 60, 0), (5, 40, 0, 0)]
+
+
+def case_random_graphs(node_len, snp, indel, sv, lib_path=None):
+    rng = np.random.default_rng(node_len * 1000 + snp)
+    g = synth.SynthGraph(synth.random_genome(25000, 500 + node_len), node_len=node_len, snp_every=snp, indel_every=indel, sv_every=sv, seed=node_len)
+    for bw, err, length, mid in [(35, 0.04, 2500, False), (35, 0.04, 2500, True), (10, 0.02, 1000, False), (64, 0.1, 1500, True), (2, 0.0, 700, False)]:
+        reads, seeds = synth.simulate_reads(g, 12, length, sub=err, ins=err, dele=err, seed=int(rng.integers(1 << 30)), mid_seed=mid)
+        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, lib_path=lib_path)
+        n_cmp = 0
+        for i, (d, o) in enumerate(zip(devs, oras)):
+            if d["status"] == 10:
+                continue      # band wider than the widest kernel variant: reported, not silently wrong
+            pc.compare_read(d, o, "nl%d bw%d read %d" % (node_len, bw, i))
+            n_cmp += 1
+        assert n_cmp >= len(reads) // 2
+
+
+def case_short_and_edge_reads(lib_path=None):
+    """directions shorter than 193 bp hit assert(samplingFrequency > 1) in the reference
+    (GraphAligner.h:906); seeds at the last base align backwards only (:3006)"""
+    g = synth.bubble_graph(20000, node_len=32, seed=21)
+    reads, seeds = synth.simulate_reads(g, 6, 1000, seed=2)
+    cases_r, cases_s = [], []
+    for r, s in zip(reads, seeds):
+        cases_r += [r[:100], r[:192], r[:193], r[:256], r, r, r]
+        cases_s += [s, s, s, s, (s[0], 1, s[2]), (s[0], len(r) - 1, s[2]), (s[0], 400, s[2])]
+    pc.check_parity(g.nodes, g.edges, cases_r, cases_s, 35, lib_path=lib_path, ctx="edge")
+
+
+def case_iupac_n_and_invalid_characters(lib_path=None):
+    g = synth.bubble_graph(20000, node_len=32, seed=22)
+    reads, seeds = synth.simulate_reads(g, 8, 1200, seed=3, mid_seed=True)
+    rng = np.random.default_rng(5)
+    out = []
+    for k, r in enumerate(reads):
+        b = bytearray(r.encode())
+        for _ in range(30):
+            b[int(rng.integers(len(b)))] = ord("NRYKMSWBDVnacgt"[int(rng.integers(15))])
+        if k == 5:
+            b[700] = ord("H")      # reverse complement of 'H' asserts in the reference (CommonUtils.cpp:128-132)
+        if k == 6:
+            b[900] = ord("X")      # characterMatch default branch (GraphAligner.h:2104)
+        if k == 7:
+            b[100] = ord("U")
+        out.append(b.decode())
+    pc.check_parity(g.nodes, g.edges, out, seeds, 35, lib_path=lib_path, ctx="iupac")
+
+
+def case_multiple_seeds_per_read(lib_path=None):
+    g = synth.bubble_graph(30000, node_len=32, seed=23)
+    reads, seeds = synth.simulate_reads(g, 6, 1500, seed=4)
+    other, oseeds = synth.simulate_reads(g, 6, 1500, seed=40, mid_seed=True)
+    multi = []
+    for s, o in zip(seeds, oseeds):
+        multi.append([s, (o[0], 700, o[2]), s, (s[0], 0, not s[2])])
+    pc.check_parity(g.nodes, g.edges, reads, multi, 35, lib_path=lib_path, ctx="multiseed")
+
+
+def case_unknown_seed_node_reports_bad_seed(lib_path=None):
+    g = synth.linear_graph(5000, node_len=64, seed=1)
+    reads, seeds = synth.simulate_reads(g, 2, 600, seed=1)
+    gg = binding.Graph(g.nodes, g.edges, lib_path=lib_path)
+    res = gg.align(reads, [(10 ** 6, 0, False), seeds[1]], 35)
+    assert res[0]["status"] == 3 and res[0]["failed"]
+    assert res[1]["status"] == 0 and not res[1]["failed"]
+
+
+def case_gfa_loader_matches_node_edge_api(lib_path=None):
+    g = synth.bubble_graph(15000, node_len=32, seed=24)
+    reads, seeds = synth.simulate_reads(g, 6, 1200, seed=8)
+    a = binding.Graph(g.nodes, g.edges, lib_path=lib_path).align(reads, seeds, 35)
+    b = binding.Graph(gfa=g.gfa(), lib_path=lib_path).align(reads, seeds, 35)
+    for x, y in zip(a, b):
+        assert x["score"] == y["score"] and x["mappings"] == y["mappings"]
+
+
+def case_full_size_properties(lib_path=None):
+    """at benchmark read length the oracle is too slow to sweep, so check size-independent
+    properties on 10 kb reads: determinism, score == edits implied by the trace, path
+    continuity, and agreement with the oracle on a small subset"""
+    g = synth.bubble_graph(400000, node_len=64, seed=44)
+    reads, seeds = synth.simulate_reads(g, 128, 10000, seed=46)
+    gg = binding.Graph(g.nodes, g.edges, lib_path=lib_path)
+    r1 = gg.align(reads, seeds, 35, flags=binding.GA_F_TRACE)
+    r2 = gg.align(reads, seeds, 35, flags=binding.GA_F_TRACE)
+    for a, b in zip(r1, r2):
+        assert a["score"] == b["score"] and a["mappings"] == b["mappings"]
+    n_ok = 0
+    for r, read in zip(r1, reads):
+        if r["failed"]:
+            continue
+        n_ok += 1
+        t = r["trace"]
+        # every mismatch / insertion / deletion costs one; padded N rows past the read end are free or insertions
+        edits = int(((t[:, 4] == 2) | (t[:, 4] == 3) | (t[:, 4] == 4)).sum())
+        assert edits <= r["score"] <= edits + 64 + 1
+        assert (np.diff(t[:, 3]) >= 0).all()
+        assert sum(m[5] for m in r["mappings"]) <= len(read)
+    assert n_ok >= 120
+    import oracle_binding as ob
+    og = ob.OracleGraph(g.nodes, g.edges)
+    for i in range(0, 128, 16):
+        pc.compare_read(r1[i], og.align(reads[i], [seeds[i]], 35), "full-size %d" % i)

@@ -1,0 +1,42 @@
+"""The device program (graphaligner_amd/csrc/ga_kernel.h) executed on the host with every wave64
+primitive emulated (tests/emul), checked against the CPU oracle.  This is how the device LOGIC
+is kept honest in the GPU-less build container; the `gpu` tests repeat the same cases through
+the real HIP library.  The emulation is test infrastructure and is never shipped."""
+import pytest
+
+import parity_cases as cases
+import parity_common as pc
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return pc.emul_lib_path()
+
+
+def test_linear(lib):
+    cases.case_wave_primitives_on_hardware(lib)
+
+
+@pytest.mark.parametrize("node_len,snp,indel,sv", cases.RANDOM_GRAPHS)
+def test_random_graphs(lib, node_len, snp, indel, sv):
+    cases.case_random_graphs(node_len, snp, indel, sv, lib)
+
+
+def test_short_and_edge_reads(lib):
+    cases.case_short_and_edge_reads(lib)
+
+
+def test_iupac_n_and_invalid_characters(lib):
+    cases.case_iupac_n_and_invalid_characters(lib)
+
+
+def test_multiple_seeds_per_read(lib):
+    cases.case_multiple_seeds_per_read(lib)
+
+
+def test_unknown_seed_node_reports_bad_seed(lib):
+    cases.case_unknown_seed_node_reports_bad_seed(lib)
+
+
+def test_gfa_loader_matches_node_edge_api(lib):
+    cases.case_gfa_loader_matches_node_edge_api(lib)

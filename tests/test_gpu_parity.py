@@ -1,0 +1,48 @@
+"""GPU parity tests: the real library (graphaligner_amd/libgraphaligner_amd.so, HIP, gfx950)
+through the C ABI against the CPU oracle on identical seeded inputs.  Bit-exact: status, score,
+node path, per-node edits (from/to length + sequence), offsets, strands, query position,
+alignment start/end, TraceItem lists, and the column-update count.  Cases: parity_cases.py."""
+import pytest
+
+import parity_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a real MI355X"
+
+
+def test_wave_primitives_on_hardware():
+    cases.case_wave_primitives_on_hardware()
+
+
+@pytest.mark.parametrize("node_len,snp,indel,sv", cases.RANDOM_GRAPHS)
+def test_random_graphs(node_len, snp, indel, sv):
+    cases.case_random_graphs(node_len, snp, indel, sv)
+
+
+def test_short_and_edge_reads():
+    cases.case_short_and_edge_reads()
+
+
+def test_iupac_n_and_invalid_characters():
+    cases.case_iupac_n_and_invalid_characters()
+
+
+def test_multiple_seeds_per_read():
+    cases.case_multiple_seeds_per_read()
+
+
+def test_unknown_seed_node_reports_bad_seed():
+    cases.case_unknown_seed_node_reports_bad_seed()
+
+
+def test_gfa_loader_matches_node_edge_api():
+    cases.case_gfa_loader_matches_node_edge_api()
+
+
+def test_full_size_properties():
+    cases.case_full_size_properties()
