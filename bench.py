@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--node-len", type=int, default=64)
     ap.add_argument("--bandwidth", type=int, default=35)
     ap.add_argument("--graph", choices=["linear", "bubbles"], default="linear")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="reads timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic build with per-phase cycle stamps (not a timed build)")
     ap.add_argument("--check", type=int, default=4, help="reads compared with the oracle after the run")
     args = ap.parse_args()
 
@@ -69,7 +70,8 @@ def main():
     reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=0.04, ins=0.04, dele=0.04, seed=43 + 1000 * rank)
     t_gen = time.time() - t0
     t0 = time.time()
-    graph = binding.Graph(gfa=g.gfa(), device=local)
+    lib_path = entry.build_stamped() if args.stamps else None
+    graph = binding.Graph(gfa=g.gfa(), device=local, lib_path=lib_path)
     batch = graph.prepare(reads, seeds, args.bandwidth, 0)
     t_prep = time.time() - t0
     total_bp = batch.total_bp
@@ -151,6 +153,11 @@ def main():
         for i in range(min(args.check, n)):
             pc.compare_read(dict(results[i], trace=np.zeros((0, 7), dtype=np.int64)), dict(og.align(reads[i], [seeds[i]], args.bandwidth), trace=np.zeros((0, 7), dtype=np.int64)), "bench read %d" % i)
         out["detail"]["oracle_spot_check_reads"] = min(args.check, n)
+    if args.stamps:
+        names = ["misc", "project_band", "topology", "order", "fill", "traceback", "trace_copy", "-"]
+        tot = float(sum(st["stamps"])) or 1.0
+        out["detail"]["phase_share"] = {n: round(v / tot, 4) for n, v in zip(names, st["stamps"])}
+        out["detail"]["cycles_per_job"] = round(tot / max(1, st["n_jobs"]))
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -50,7 +50,7 @@ class GaResults(C.Structure):
 class GaBatchStats(C.Structure):
     _fields_ = [("n_jobs", C.c_uint64), ("column_updates", C.c_uint64), ("slices", C.c_uint64), ("jobs_retried", C.c_uint64),
                 ("kernel_ms", C.c_double), ("prep_kernel_ms", C.c_double), ("slots", C.c_uint32), ("waves_per_cu", C.c_uint32),
-                ("scratch_bytes", C.c_uint64)]
+                ("scratch_bytes", C.c_uint64), ("stamps", C.c_uint64 * 8)]
 
 
 EXPORTS = ["ga_graph_create", "ga_graph_destroy", "ga_graph_add_node", "ga_graph_add_edge", "ga_graph_add_bigraph_node",
@@ -178,7 +178,9 @@ class Batch:
     def stats(self):
         st = GaBatchStats()
         _check(self.L, self.L.ga_batch_stats(self.h, C.byref(st)), "ga_batch_stats")
-        return {k: getattr(st, k) for k, _ in st._fields_}
+        d = {k: getattr(st, k) for k, _ in st._fields_}
+        d["stamps"] = list(st.stamps)
+        return d
 
     def collect(self):
         out = C.POINTER(GaResults)()

@@ -30,6 +30,7 @@ struct GaRunStats
 	uint32_t slots = 0, waves_per_cu = 0;
 	uint64_t scratch_bytes = 0;
 	uint64_t jobs_retried = 0;
+	uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic builds: summed shader cycles per phase
 };
 
 class GaBackendGraph { public: virtual ~GaBackendGraph() {} };

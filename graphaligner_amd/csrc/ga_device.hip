@@ -180,6 +180,7 @@ struct DevBatch : GaBackendBatch
 		float ms = 0;
 		HIP_OK(hipEventElapsedTime(&ms, evStart, evStop));
 		st.kernel_ms = ms;
+		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
 		// ---- capacity misses go through the wide variant (256 band nodes in LDS, larger buffers) ----
 		std::vector<uint32_t> again;
 		for (uint32_t i = 0; i < outs.size(); i++)

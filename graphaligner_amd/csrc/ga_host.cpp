@@ -586,6 +586,7 @@ int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out)
 	out->waves_per_cu = st.waves_per_cu;
 	out->scratch_bytes = st.scratch_bytes;
 	out->jobs_retried = st.jobs_retried;
+	for (int k = 0; k < 8; k++) out->stamps[k] = st.stamps[k];
 	out->column_updates = b->columnUpdates;
 	out->slices = b->slicesRun;
 	return GA_S_OK;

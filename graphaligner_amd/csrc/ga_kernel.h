@@ -26,11 +26,12 @@ using namespace gaw;
 constexpr int W = 64;
 constexpr uint32_t kCutoff = 200000;         // GraphAlignerCommon.h:10
 constexpr int kSliceHdrWords = 6;
+constexpr int kNbr = 4;                      // neighbours per band node cached in LDS
 
 template <int MAXN> struct Limits
 {
 	static constexpr int kBuckets = MAXN <= 13 ? 13 : MAXN <= 29 ? 29 : MAXN <= 59 ? 59 : MAXN <= 127 ? 127 : 257;   // libstdc++ growth: 13,29,59,127,257
-	static constexpr int kHeap = 6 * MAXN;
+	static constexpr int kHeap = 4 * MAXN;
 	static_assert(MAXN <= 257, "bucket schedule only covers 257 band nodes");
 };
 
@@ -43,6 +44,9 @@ template <int MAXN> struct WaveState
 	int32_t pn_lastEnd[MAXN];    // scoreEnd of the node's last column
 	int32_t pn_lastEnd2[MAXN];   // score one row above it (scoreEnd -/+ last VP/VN bit)
 	uint32_t pn_colBase[MAXN];   // first column of the node inside the previous end buffer
+	uint32_t pn_len[MAXN];
+	uint8_t pn_outDeg[MAXN];     // > kNbr: the list lives in HBM only
+	uint32_t pn_outNbr[MAXN * 4];
 	// current band, in band order
 	uint32_t cn_node[MAXN];
 	uint32_t cn_colBase[MAXN];
@@ -55,6 +59,10 @@ template <int MAXN> struct WaveState
 	uint64_t cn_lastVN[MAXN];
 	int32_t cn_lastBefore[MAXN];
 	uint8_t cn_lastExists[MAXN];
+	// topology of the band nodes, fetched once per slice with all lanes in parallel
+	uint32_t cn_startLo[MAXN], cn_startHi[MAXN];   // first column of the node in the graph
+	uint8_t cn_inDeg[MAXN], cn_outDeg[MAXN];      // > kNbr: the list lives in HBM only
+	uint32_t cn_inNbr[MAXN * 4], cn_outNbr[MAXN * 4];
 	uint8_t color[MAXN];
 	int16_t post[MAXN];          // Tarjan emission order
 	// scratch: hash-order emulation / heap / DFS stack
@@ -197,9 +205,8 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 	totalCols = 0;
 	int heapSize = 0;
 	hash_order(ws, ws.pn_node, pn);
-	auto add = [&](uint32_t node, int prevSlot) -> bool {
+	auto add = [&](uint32_t node, int prevSlot, uint32_t len) -> bool {
 		if (cn >= MAXN) return false;
-		uint32_t len = g_len(g, node);
 		ws.cn_node[cn] = node;
 		ws.cn_prev[cn] = (int16_t)prevSlot;
 		ws.cn_len[cn] = len;
@@ -213,12 +220,21 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 		int s = ws.h_order[k];
 		if (ws.pn_min[s] > prevMin + bandwidth) continue;
 		uint32_t node = ws.pn_node[s];
-		if (!add(node, s)) return GA_CAP_NODES;
+		if (!add(node, s, ws.pn_len[s])) return GA_CAP_NODES;
 		if (totalCols >= kCutoff) return GA_UNSUPPORTED_BAND;
 		int endScore = ws.pn_lastEnd[s];
 		if (endScore > prevMin + expand) continue;
-		for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
-			if (!heap_push(ws, heapSize, g.out_nbr[e], endScore - prevMin + 1)) return GA_CAP_HEAP;
+		int deg = ws.pn_outDeg[s];
+		if (deg <= kNbr)
+		{
+			for (int e = 0; e < deg; e++)
+				if (!heap_push(ws, heapSize, ws.pn_outNbr[s * kNbr + e], endScore - prevMin + 1)) return GA_CAP_HEAP;
+		}
+		else
+		{
+			for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
+				if (!heap_push(ws, heapSize, g.out_nbr[e], endScore - prevMin + 1)) return GA_CAP_HEAP;
+		}
 	}
 	if (cn == 0) return GA_ASSERTION;                                   // assert(distances.size() > 0) (:1138)
 	while (heapSize > 0)
@@ -228,13 +244,75 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 		if (prio > expand) break;
 		heap_pop(ws, heapSize);
 		if (find_slot(ws.cn_node, cn, node) >= 0) continue;             // already at a distance <= prio
-		if (!add(node, find_slot(ws.pn_node, pn, node))) return GA_CAP_NODES;
+		int ps = find_slot(ws.pn_node, pn, node);
+		uint32_t len = ps >= 0 ? ws.pn_len[ps] : g_len(g, node);
+		if (!add(node, ps, len)) return GA_CAP_NODES;
 		if (totalCols >= kCutoff) return GA_UNSUPPORTED_BAND;
-		int len = (int)ws.cn_len[cn - 1];
-		for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
-			if (!heap_push(ws, heapSize, g.out_nbr[e], prio + len)) return GA_CAP_HEAP;
+		if (ps >= 0 && ws.pn_outDeg[ps] <= kNbr)
+		{
+			for (int e = 0; e < ws.pn_outDeg[ps]; e++)
+				if (!heap_push(ws, heapSize, ws.pn_outNbr[ps * kNbr + e], prio + (int)len)) return GA_CAP_HEAP;
+		}
+		else
+		{
+			for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
+				if (!heap_push(ws, heapSize, g.out_nbr[e], prio + (int)len)) return GA_CAP_HEAP;
+		}
 	}
 	return GA_OK;
+}
+
+// ---- fetch the band nodes' topology into LDS: lanes = band nodes, one round trip to HBM/L2 ------------
+template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN>& ws, int cn)
+{
+	const VI lane = lane_iota();
+	const uint32_t* startWords = (const uint32_t*)g.node_start;
+	for (int base = 0; base < cn; base += LANES)
+	{
+		VB live = lane < (cn - base);
+		VI slot = lane + base;
+		VI node = select(live, load_lanes(ws.cn_node + base, cn - base, 0), VI(0));
+		VI lo = gather(startWords, node + node);
+		VI hi = gather(startWords, node + node + 1);
+		VI in0 = gather(g.in_off, node), in1 = gather(g.in_off, node + 1);
+		VI out0 = gather(g.out_off, node), out1 = gather(g.out_off, node + 1);
+		VI inDeg = in1 - in0, outDeg = out1 - out0;
+		scatter(ws.cn_startLo, slot, lo, live);
+		scatter(ws.cn_startHi, slot, hi, live);
+		scatter(ws.cn_inDeg, slot, vmin(inDeg, VI(255)), live);
+		scatter(ws.cn_outDeg, slot, vmin(outDeg, VI(255)), live);
+		for (int k = 0; k < kNbr; k++)
+		{
+			VB hasIn = live && (VI(k) < inDeg);
+			VB hasOut = live && (VI(k) < outDeg);
+			VI inN = gather(g.in_nbr, select(hasIn, in0 + k, VI(0)));
+			VI outN = gather(g.out_nbr, select(hasOut, out0 + k, VI(0)));
+			scatter(ws.cn_inNbr, (slot << 2) + k, inN, hasIn);
+			scatter(ws.cn_outNbr, (slot << 2) + k, outN, hasOut);
+		}
+	}
+}
+
+// the k-th in / out neighbour of band slot s (LDS copy, HBM beyond kNbr)
+template <int MAXN> GA_FN uint32_t in_neighbor(const GaDevGraph& g, const WaveState<MAXN>& ws, int s, int k)
+{
+	if (ws.cn_inDeg[s] <= kNbr) return ws.cn_inNbr[s * kNbr + k];
+	return g.in_nbr[g.in_off[ws.cn_node[s]] + k];
+}
+template <int MAXN> GA_FN int in_degree(const GaDevGraph& g, const WaveState<MAXN>& ws, int s)
+{
+	if (ws.cn_inDeg[s] <= kNbr) return ws.cn_inDeg[s];
+	return (int)(g.in_off[ws.cn_node[s] + 1] - g.in_off[ws.cn_node[s]]);
+}
+template <int MAXN> GA_FN uint32_t out_neighbor(const GaDevGraph& g, const WaveState<MAXN>& ws, int s, int k)
+{
+	if (ws.cn_outDeg[s] <= kNbr) return ws.cn_outNbr[s * kNbr + k];
+	return g.out_nbr[g.out_off[ws.cn_node[s]] + k];
+}
+template <int MAXN> GA_FN int out_degree(const GaDevGraph& g, const WaveState<MAXN>& ws, int s)
+{
+	if (ws.cn_outDeg[s] <= kNbr) return ws.cn_outDeg[s];
+	return (int)(g.out_off[ws.cn_node[s] + 1] - g.out_off[ws.cn_node[s]]);
 }
 
 // ---- processing order: reverse Tarjan emission order over the band subgraph (:1836-1901, :2360) ----
@@ -242,7 +320,7 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 // node still on the DFS stack means a cycle, which this kernel does not handle.
 template <int MAXN> GA_FN int processing_order(const GaDevGraph& g, WaveState<MAXN>& ws, int cn)
 {
-	for (int i = 0; i < cn; i++) ws.color[i] = 0;
+	for (int c = 0; c < cn; c += LANES) store_lanes(ws.color + c, cn - c, VI(0));
 	int emitted = 0;
 	for (int root = 0; root < cn; root++)
 	{
@@ -250,21 +328,20 @@ template <int MAXN> GA_FN int processing_order(const GaDevGraph& g, WaveState<MA
 		int sp = 0;
 		ws.color[root] = 1;
 		ws.st_slot[0] = (int16_t)root;
-		ws.st_cur[0] = g.out_off[ws.cn_node[root]];
+		ws.st_cur[0] = 0;
 		sp = 1;
 		while (sp > 0)
 		{
 			int v = ws.st_slot[sp - 1];
-			uint32_t cur = ws.st_cur[sp - 1];
-			uint32_t end = g.out_off[ws.cn_node[v] + 1];
-			if (cur < end)
+			int cur = (int)ws.st_cur[sp - 1];
+			if (cur < out_degree(g, ws, v))
 			{
-				int x = find_slot(ws.cn_node, cn, g.out_nbr[cur]);
-				if (x < 0 || ws.color[x] == 2) { ws.st_cur[sp - 1] = cur + 1; continue; }
+				int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, v, cur));
+				if (x < 0 || ws.color[x] == 2) { ws.st_cur[sp - 1] = (uint32_t)(cur + 1); continue; }
 				if (ws.color[x] == 1) return GA_UNSUPPORTED_CYCLE;
 				ws.color[x] = 1;
 				ws.st_slot[sp] = (int16_t)x;
-				ws.st_cur[sp] = g.out_off[ws.cn_node[x]];
+				ws.st_cur[sp] = 0;
 				sp++;
 				continue;
 			}
@@ -334,7 +411,6 @@ template <int MAXN>
 GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const uint8_t* rows, uint32_t nRows,
                      uint32_t j, int pn, int cn, int& sliceMin, int& minSlot, uint32_t& minOffset)
 {
-	(void)pn;
 	const VI lane = lane_iota();
 	const VU lowMask = low_mask_through_lane();
 	const VI rowCode = load_lanes(rows + j, W, 0);
@@ -350,9 +426,8 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 	for (int oi = cn - 1; oi >= 0; oi--)
 	{
 		const int s = ws.post[oi];
-		const uint32_t node = ws.cn_node[s];
 		const uint32_t len = ws.cn_len[s];
-		const uint64_t firstCol = g.node_start[node];
+		const uint64_t firstCol = ((uint64_t)ws.cn_startHi[s] << 32) | ws.cn_startLo[s];
 		const int ps = ws.cn_prev[s];
 		const bool inPrev = ps >= 0;
 		const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
@@ -360,12 +435,26 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		if (sink.fill && sink.flushed + sink.fill != ws.cn_colBase[s]) flush_columns<MAXN>(sink, rec, slot.end_cur);
 		if (sink.fill == 0) sink.flushed = ws.cn_colBase[s];
 
+		// ---- the node's graph bases and previous-slice end scores, 64 columns at a time, one lane each ----
+		const uint32_t bit0 = (uint32_t)(firstCol & 15);
+		const uint32_t* seqWords = g.seq2 + (firstCol >> 4);
+		VI baseChunk, pendChunk;
+		auto loadChunk = [&](uint32_t w0) {
+			VI at = lane + (int)(bit0 + w0);
+			baseChunk = (gather(seqWords, at >> 4) >> ((at & 15) << 1)) & 3;
+			pendChunk = inPrev ? load_lanes(pend + w0, (int)(len - w0), 0) : VI(0);
+		};
+		loadChunk(0);
+
 		// --- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ---
-		int zero0 = inPrev ? (int)(pend[0] >> 2) : INF;
+		const int inDeg = in_degree(g, ws, s);
+		int pend0raw = read_lane(pendChunk, 0);
+		int pend0 = inPrev ? (pend0raw >> 2) : INF;
+		int zero0 = pend0;
 		bool hasIn = false;
-		for (uint32_t e = g.in_off[node]; e < g.in_off[node + 1]; e++)
+		for (int e = 0; e < inDeg; e++)
 		{
-			uint32_t m = g.in_nbr[e];
+			uint32_t m = in_neighbor(g, ws, s, e);
 			int cs = find_slot(ws.cn_node, cn, m);
 			int pm = find_slot(ws.pn_node, pn, m);
 			if (cs < 0 && pm < 0) continue;
@@ -373,10 +462,9 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			if (cs >= 0) zero0 = zero0 < ws.cn_lastBefore[cs] + 1 ? zero0 : ws.cn_lastBefore[cs] + 1;
 			if (pm >= 0) zero0 = zero0 < ws.pn_lastEnd[pm] + 1 ? zero0 : ws.pn_lastEnd[pm] + 1;
 		}
-		int base = g_base(g, firstCol);
+		int base = read_lane(baseChunk, 0);
 		VI eqLane = (rowCode >> base) & 1;
 		bool aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);       // "previousEq": raw char ==, not characterMatch (:1503)
-		int pend0 = inPrev ? (int)(pend[0] >> 2) : INF;
 		bool exists0 = inPrev && pend0 == zero0;                                 // scoreBeforeExists from :1989 (scoreEndExists is always true here)
 		VI S;
 		int before;
@@ -409,9 +497,9 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			// node start: cell-wise min over the in-neighbours' last columns advanced one step (:1270-1315)
 			VI H = VI(INF);
 			int calc = INF;
-			for (uint32_t e = g.in_off[node]; e < g.in_off[node + 1]; e++)
+			for (int e = 0; e < inDeg; e++)
 			{
-				uint32_t m = g.in_nbr[e];
+				uint32_t m = in_neighbor(g, ws, s, e);
 				int cs = find_slot(ws.cn_node, cn, m);
 				int pm = find_slot(ws.pn_node, pn, m);
 				if (cs < 0 && pm < 0) continue;
@@ -453,6 +541,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 
 		int nodeMin = INF;
 		int zero = zero0;
+		uint32_t pendLeftRaw = (uint32_t)pend0raw;                              // packed end word of the column to the left, previous slice
 		for (uint32_t w = 0;; w++)
 		{
 			// ---- emit column w ----
@@ -483,10 +572,13 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				break;
 			}
 			// ---- column w+1 from column w (calculateNode inner loop :1533-1546, getNextSlice :1349-1427) ----
-			base = g_base(g, firstCol + w + 1);
+			const uint32_t wn = w + 1;
+			if ((wn & (LANES - 1)) == 0) loadChunk(wn);
+			base = read_lane(baseChunk, (int)(wn & (LANES - 1)));
 			eqLane = (rowCode >> base) & 1;
 			aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);
-			int pendW = inPrev ? (int)(pend[w + 1] >> 2) : INF;
+			uint32_t pendRaw = (uint32_t)read_lane(pendChunk, (int)(wn & (LANES - 1)));
+			int pendW = inPrev ? (int)(pendRaw >> 2) : INF;
 			zero = zero + 1 < pendW ? zero + 1 : pendW;                         // row j-1 chain (:1939-1944)
 			bool existsW = inPrev && pendW == zero;
 			VI eq = exists ? eqLane : select(lane == 0, VI(0), eqLane);
@@ -495,8 +587,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			int calc = before + 1;
 			if (existsW)
 			{
-				uint32_t pl = pend[w];
-				int aboveLeft2 = (int)(pl >> 2) - (int)(pl & 1) + (int)((pl >> 1) & 1);
+				int aboveLeft2 = (int)(pendLeftRaw >> 2) - (int)(pendLeftRaw & 1) + (int)((pendLeftRaw >> 1) & 1);
 				int viaDiag = aboveLeft2 + (aboveEq ? 0 : 1);
 				calc = calc < viaDiag ? calc : viaDiag;
 			}
@@ -505,6 +596,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			exists = reenter ? true : existsW;
 			VI pmn = prefix_min(H - lane);
 			S = vmin(pmn + lane, lane + (before + 1));
+			pendLeftRaw = pendRaw;
 		}
 	}
 	flush_columns<MAXN>(sink, rec, slot.end_cur);
@@ -535,6 +627,9 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	Slot slot = slotIn;
 	GaJobOut out;
 	out.status = GA_OK; out.score = 0x7fffffff; out.n_valid = 0; out.n_run = 0; out.trace_len = 0; out.max_band_nodes = 0; out.n_columns = 0; out.trace_off = 0;
+	for (int i = 0; i < 8; i++) out.stamps[i] = 0;
+	uint64_t tA = stamp(), tB;
+#define GA_LAP(i) do { tB = stamp(); out.stamps[i] += tB - tA; tA = tB; } while (0)
 	const uint32_t numSlices = job.n_rows / W;
 	int status = GA_OK;
 
@@ -547,6 +642,8 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		if (GA_LANE0)
 		{
 			ws.pn_node[0] = job.seed_node; ws.pn_min[0] = 0; ws.pn_lastEnd[0] = 0; ws.pn_lastEnd2[0] = 0; ws.pn_colBase[0] = 0;
+			ws.pn_len[0] = seedLen;
+			ws.pn_outDeg[0] = 255;          // the seed node's out-list is read from HBM once
 		}
 		for (uint32_t c = 0; c < seedLen; c += LANES) store_lanes(slot.end_prev + c, (int)(seedLen - c), VI(0));
 	}
@@ -564,11 +661,17 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		const int bandwidth = slice == 0 ? L.ramp_bw : L.initial_bw;
 		int cn = 0;
 		uint32_t totalCols = 0;
+		GA_LAP(0);
 		status = project_band(g, ws, pn, prevMin, bandwidth, cn, totalCols);
+		GA_LAP(1);
 		if (status != GA_OK) break;
 		if (totalCols > L.cap_cols) { status = GA_CAP_COLS; break; }
 		wave_sync();
+		load_topology(g, ws, cn);
+		wave_sync();
+		GA_LAP(2);
 		status = processing_order(g, ws, cn);
+		GA_LAP(3);
 		if (status != GA_OK) break;
 		uint64_t need = slice_words((uint32_t)cn, totalCols);
 		if (arenaTop + need > L.arena_words) { status = GA_CAP_ARENA; break; }
@@ -581,7 +684,9 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		wave_sync();
 		int sliceMin, minSlot;
 		uint32_t minOffset;
+		GA_LAP(0);
 		status = fill_slice(g, ws, slot, rec, rows, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
+		GA_LAP(4);
 		if (status != GA_OK) break;
 		if (sliceMin < prevMin) { status = GA_ASSERTION; break; }                 // :2469
 		if (GA_LANE0)
@@ -616,13 +721,17 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			store_lanes(ws.pn_lastEnd + c, k, load_lanes(ws.cn_lastEnd + c, k, 0));
 			store_lanes(ws.pn_lastEnd2 + c, k, load_lanes(ws.cn_lastEnd2 + c, k, 0));
 			store_lanes(ws.pn_colBase + c, k, load_lanes(ws.cn_colBase + c, k, 0));
+			store_lanes(ws.pn_len + c, k, load_lanes(ws.cn_len + c, k, 0));
+			store_lanes(ws.pn_outDeg + c, k, load_lanes(ws.cn_outDeg + c, k, 0));
 		}
+		for (int c = 0; c < cn * kNbr; c += LANES) store_lanes(ws.pn_outNbr + c, cn * kNbr - c, load_lanes(ws.cn_outNbr + c, cn * kNbr - c, 0));
 		pn = cn;
 		prevMin = sliceMin;
 		uint32_t* t = slot.end_prev; slot.end_prev = slot.end_cur; slot.end_cur = t;
 		wave_sync();
 	}
 	out.n_run = nRun;
+	GA_LAP(0);
 
 	// ---- drop the wrongly aligned tail (removeWronglyAlignedEnd, :2554-2569) ----
 	uint32_t kept = nPushed;
@@ -657,21 +766,46 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		uint32_t offset = cur.hdr[4];
 		uint32_t row = sIdx * W + (W - 1);
 		uint32_t len = 0;
-		bool havePrev = false;
 		SliceRec prv = cur;
 		uint32_t pN = 0;
 		auto loadPrev = [&]() {
-			if (sIdx == 0) { havePrev = false; return; }
+			if (sIdx == 0) return;
 			uint32_t o = slot.slice_off[sIdx - 1];
 			pN = slot.arena[o];
 			prv = slice_at(slot.arena, o, pN, slot.arena[o + 1]);
-			havePrev = true;
 		};
 		loadPrev();
 		auto valuePrevLastRow = [&](uint32_t n, uint32_t o2) -> int {
 			// row 63 of the slice before; before slice 0 that is the all-zero seed slice
 			if (sIdx == 0) return n == job.seed_node ? 0 : big;
 			return stored_value(prv, pN, n, o2, W - 1, big);
+		};
+		// A window = up to 64 consecutive columns of one node in one slice, one column per lane, so a
+		// run of steps inside a node costs no memory round trips: every lane evaluates its column
+		// at the wanted row (WordSlice.h:223-229) and the few values a step needs are read back.
+		struct Window { VU vp, vn; VI before; uint32_t slice, node; int lo, n; bool valid, present; };
+		Window cw, pw;
+		cw.valid = false; pw.valid = false;
+		cw.vp = VU(0); cw.vn = VU(0); cw.before = VI(0); pw.vp = VU(0); pw.vn = VU(0); pw.before = VI(0);
+		cw.slice = cw.node = pw.slice = pw.node = 0; cw.lo = cw.n = pw.lo = pw.n = 0; cw.present = pw.present = false;
+		VI winBases = VI(0);
+		VI rowv = load_lanes(rows + sIdx * W, W, 0);
+		uint32_t rowvSlice = sIdx;
+		const VI lane = lane_iota();
+		auto loadWindow = [&](Window& w, const SliceRec& rec, uint32_t recNodes, uint32_t sliceIdx, uint32_t n, uint32_t hiOffset) {
+			w.slice = sliceIdx; w.node = n;
+			w.lo = hiOffset >= (uint32_t)(LANES - 1) ? (int)(hiOffset - (LANES - 1)) : 0;
+			w.n = (int)hiOffset - w.lo + 1;
+			int sl = find_slot(rec.nodes, (int)recNodes, n);
+			w.present = sl >= 0;
+			w.valid = true;
+			if (sl >= 0)
+			{
+				uint32_t at = rec.colBase[sl] + (uint32_t)w.lo;
+				w.vp = load_lanes_u64(rec.vp + at, w.n);
+				w.vn = load_lanes_u64(rec.vn + at, w.n);
+				w.before = load_lanes(rec.before + at, w.n, 0);
+			}
 		};
 		while (true)
 		{
@@ -680,17 +814,58 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			len++;
 			if (row == 0xffffffffu) break;                                       // reached the row before the first one
 			const int r = (int)(row - sIdx * W);
-			const int here = stored_value(cur, nN, node, offset, r, big);
+			if (rowvSlice != sIdx) { rowv = load_lanes(rows + sIdx * W, W, 0); rowvSlice = sIdx; }
+			// ---- make the current window cover this column (and its left neighbour when there is one) ----
+			bool covers = cw.valid && cw.slice == sIdx && cw.node == node && (int)offset >= cw.lo && (int)offset < cw.lo + cw.n && !((int)offset == cw.lo && offset > 0);
+			if (!covers)
+			{
+				if (pw.valid && pw.slice == sIdx && pw.node == node && (int)offset >= pw.lo && (int)offset < pw.lo + pw.n && !((int)offset == pw.lo && offset > 0))
+				{
+					cw = pw;                                                   // the window fetched for the slice boundary becomes current
+				}
+				else
+				{
+					loadWindow(cw, cur, nN, sIdx, node, offset);
+					const uint64_t firstCol = g.node_start[node] + (uint32_t)cw.lo;
+					VI at = lane + (int)(firstCol & 15);
+					winBases = (gather(g.seq2 + (firstCol >> 4), at >> 4) >> ((at & 15) << 1)) & 3;
+				}
+				pw.valid = false;
+			}
+			if (!cw.present) { status = GA_ASSERTION; break; }                   // assert(slice.scores.hasNode(nodeIndex)) (:498)
+			const int rel = (int)offset - cw.lo;
+			const uint64_t maskR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull;
+			const VI valR = cw.before + vpopc(maskR & cw.vp) - vpopc(maskR & cw.vn);
+			const int here = read_lane(valR, rel);
 			if (row == 0 && node == job.seed_node && (here == 0 || here == 1)) { row = 0xffffffffu; continue; }   // free start (:500)
-			const int rowCode = rows[row];
-			const int base = g_base(g, g.node_start[node] + offset);
+			const int rowCode = read_lane(rowv, r);
+			const int base = read_lane(winBases, rel);
 			const bool match = (rowCode >> base) & 1;
-			bool moved = false;
-			auto tryFrom = [&](uint32_t un, uint32_t uo) -> int {
-				int horizontal = stored_value(cur, nN, un, uo, r, big);
+			// values one row up: same window for r > 0, the slice above (its row 63) for r == 0
+			VI valUp;
+			bool upKnown = true;
+			if (r > 0)
+			{
+				const uint64_t maskU = ~(~0ull << r);
+				valUp = cw.before + vpopc(maskU & cw.vp) - vpopc(maskU & cw.vn);
+			}
+			else if (sIdx == 0)
+			{
+				valUp = VI(node == job.seed_node ? 0 : big);
+			}
+			else
+			{
+				if (!(pw.valid && pw.slice == sIdx - 1 && pw.node == node && pw.lo == cw.lo && pw.n == cw.n))
+					loadWindow(pw, prv, pN, sIdx - 1, node, (uint32_t)(cw.lo + cw.n - 1));
+				if (pw.present) valUp = pw.before + vpopc(pw.vp) - vpopc(pw.vn);
+				else valUp = VI(big);
+			}
+			(void)upKnown;
+			int res = 0;
+			const uint32_t curNode = node, curOffset = offset;
+			auto decide = [&](int horizontal, int diagonal, uint32_t un, uint32_t uo) -> int {
 				if (horizontal < here - 1) return -1;
 				if (horizontal == here - 1) { node = un; offset = uo; return 1; }
-				int diagonal = r == 0 ? valuePrevLastRow(un, uo) : stored_value(cur, nN, un, uo, r - 1, big);
 				if (match)
 				{
 					if (diagonal < here) return -1;
@@ -703,27 +878,28 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				}
 				return 0;
 			};
-			int res = 0;
-			const uint32_t curNode = node, curOffset = offset;
 			if (curOffset == 0)
 			{
 				for (uint32_t e = g.in_off[curNode]; e < g.in_off[curNode + 1] && res == 0; e++)
 				{
 					uint32_t m = g.in_nbr[e];
-					res = tryFrom(m, g_len(g, m) - 1);
+					uint32_t mo = g_len(g, m) - 1;
+					int horizontal = stored_value(cur, nN, m, mo, r, big);
+					int diagonal = 0;
+					if (horizontal > here - 1) diagonal = r == 0 ? valuePrevLastRow(m, mo) : stored_value(cur, nN, m, mo, r - 1, big);
+					res = decide(horizontal, diagonal, m, mo);
 				}
 			}
-			else res = tryFrom(curNode, curOffset - 1);
+			else res = decide(read_lane(valR, rel - 1), read_lane(valUp, rel - 1), curNode, curOffset - 1);
 			if (res < 0) { status = GA_ASSERTION; break; }
 			if (res == 0)
 			{
-				int up = r == 0 ? valuePrevLastRow(curNode, curOffset) : stored_value(cur, nN, curNode, curOffset, r - 1, big);
+				int up = read_lane(valUp, rel);
 				if (up != here - 1) { status = GA_ASSERTION; break; }            // assert(false) (:588)
 				row = row - 1;
 				res = 2;
 			}
-			moved = res == 2;
-			if (moved && r == 0 && row != 0xffffffffu)
+			if (res == 2 && r == 0 && row != 0xffffffffu)
 			{
 				// stepped into the slice above
 				sIdx--;
@@ -731,6 +907,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				loadPrev();
 			}
 		}
+		GA_LAP(5);
 		// hand the steps over: claim exactly `len` entries of the pool and copy them, 64 at a time
 		if (status == GA_OK)
 		{
@@ -747,6 +924,8 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			}
 		}
 	}
+	GA_LAP(6);
+#undef GA_LAP
 	out.status = status;
 	if (GA_LANE0) L.outs[jobIndex] = out;
 }

@@ -53,6 +53,7 @@ struct GaJobOut {
 	uint32_t max_band_nodes;
 	uint64_t n_columns;    // column updates = sum over computed slices of band columns
 	uint64_t trace_off;    // first step of this job inside the trace pool
+	uint64_t stamps[8];    // diagnostic builds only (GA_STAMPS): shader cycles per phase; zero otherwise
 };
 
 struct GaTraceStep { uint32_t node, offset, row; };

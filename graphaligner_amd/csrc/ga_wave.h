@@ -72,7 +72,12 @@ inline uint64_t read_lane(const VU& x, int lane) { return x.v[lane]; }
 template <typename T> inline VI load_lanes(const T* p, int count, int fill) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = i < count ? (int)p[i] : fill; return r; }
 template <typename T> inline void store_lanes(T* p, int count, const VI& x) { for (int i = 0; i < LANES && i < count; i++) p[i] = (T)x.v[i]; }
 inline void store_lanes(uint64_t* p, int count, const VU& x) { for (int i = 0; i < LANES && i < count; i++) p[i] = x.v[i]; }
+inline VU load_lanes_u64(const uint64_t* p, int count) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = i < count ? p[i] : 0; return r; }
+// per-lane indexed load / masked indexed store
+template <typename T> inline VI gather(const T* p, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)p[idx.v[i]]; return r; }
+template <typename T> inline void scatter(T* p, const VI& idx, const VI& x, const VB& m) { for (int i = 0; i < LANES; i++) if (m.v[i]) p[idx.v[i]] = (T)x.v[i]; }
 inline void wave_sync() {}
+inline uint64_t stamp() { return 0; }
 // one reservation for the whole wave; every lane sees the old value
 inline uint64_t wave_atomic_add(uint64_t* p, uint64_t v) { uint64_t r = *p; *p += v; return r; }
 inline uint32_t wave_atomic_add(uint32_t* p, uint32_t v) { uint32_t r = *p; *p += v; return r; }
@@ -120,8 +125,16 @@ GA_FN uint64_t read_lane(VU x, int lane)
 template <typename T> GA_FN VI load_lanes(const T* p, int count, int fill) { return (int)threadIdx.x < count ? (int)p[threadIdx.x] : fill; }
 template <typename T> GA_FN void store_lanes(T* p, int count, VI x) { if ((int)threadIdx.x < count) p[threadIdx.x] = (T)x; }
 GA_FN void store_lanes(uint64_t* p, int count, VU x) { if ((int)threadIdx.x < count) p[threadIdx.x] = x; }
+GA_FN VU load_lanes_u64(const uint64_t* p, int count) { return (int)threadIdx.x < count ? p[threadIdx.x] : 0ull; }
+template <typename T> GA_FN VI gather(const T* p, VI idx) { return (int)p[idx]; }
+template <typename T> GA_FN void scatter(T* p, VI idx, VI x, VB m) { if (m) p[idx] = (T)x; }
 // one wave per workgroup: orders this wave's LDS / global traffic (s_waitcnt + s_barrier)
 GA_FN void wave_sync() { __syncthreads(); }
+#ifdef GA_STAMPS
+GA_FN uint64_t stamp() { return __builtin_readcyclecounter(); }
+#else
+GA_FN uint64_t stamp() { return 0; }
+#endif
 // lane 0 performs the device-scope atomic, the old value is broadcast to the wave
 GA_FN uint32_t wave_atomic_add(uint32_t* p, uint32_t v)
 {

@@ -150,6 +150,7 @@ typedef struct ga_batch_stats {
 	double prep_kernel_ms;       /* HIP-event time of the read-coding kernel */
 	uint32_t slots, waves_per_cu;
 	uint64_t scratch_bytes;
+	uint64_t stamps[8];          /* diagnostic builds (GA_STAMPS) only: shader cycles per phase, summed over jobs */
 } ga_batch_stats_t;
 int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out);
 
