@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--graph", choices=["linear", "bubbles"], default="linear")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build with per-phase cycle stamps (not a timed build)")
+    ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
     ap.add_argument("--check", type=int, default=4, help="reads compared with the oracle after the run")
     args = ap.parse_args()
 
@@ -70,7 +71,7 @@ def main():
     reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=0.04, ins=0.04, dele=0.04, seed=43 + 1000 * rank)
     t_gen = time.time() - t0
     t0 = time.time()
-    lib_path = entry.build_stamped() if args.stamps else None
+    lib_path = entry.build_stamped() if args.stamps else args.lib
     graph = binding.Graph(gfa=g.gfa(), device=local, lib_path=lib_path)
     batch = graph.prepare(reads, seeds, args.bandwidth, 0)
     t_prep = time.time() - t0

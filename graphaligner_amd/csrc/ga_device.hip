@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,8 +38,11 @@ __host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxS
 	return l;
 }
 
+#ifndef GA_WAVES_EU
+#define GA_WAVES_EU 4
+#endif
 template <int MAXN>
-__global__ void __launch_bounds__(64) ga_extend_kernel(GaLaunch L)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GA_WAVES_EU, 8))) ga_extend_kernel(GaLaunch L)
 {
 	__shared__ gak::WaveState<MAXN> ws;
 	const SlotLayout lay = slotLayout(L.cap_cols, L.max_slices, L.arena_words, L.trace_cap);
@@ -89,6 +93,7 @@ struct DevBatch : GaBackendBatch
 	GaRunConfig cfg;
 	GaLaunch L;                 // main launch
 	uint32_t slots = 0, wavesPerCu = 0;
+	bool narrow = true;         // first pass with the 32-node variant (more waves per CU); misses go to the 256-node variant
 	std::vector<GaJobOut> outs;
 	GaRunStats st;
 	// retry pass (wide variant), built lazily
@@ -152,7 +157,8 @@ struct DevBatch : GaBackendBatch
 		L.slot_bytes = lay.bytes;
 		size_t freeB = 0, totalB = 0;
 		HIP_OK(hipMemGetInfo(&freeB, &totalB));
-		wavesPerCu = 16;
+		wavesPerCu = getenv("GA_WAVES_PER_CU") ? (uint32_t)atoi(getenv("GA_WAVES_PER_CU")) : 24;
+		narrow = !(getenv("GA_NARROW") && atoi(getenv("GA_NARROW")) == 0);
 		uint64_t want = (uint64_t)g->cus * wavesPerCu;
 		uint64_t fit = (uint64_t)(freeB * 0.8) / std::max<uint64_t>(lay.bytes, 1);
 		slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(want, fit), std::max<size_t>(jobs.size(), 1)));
@@ -171,7 +177,8 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipMemsetAsync(L.next_job, 0, 16, stream));
 		HIP_OK(hipMemsetAsync(L.trace_top, 0, 16, stream));
 		HIP_OK(hipEventRecord(evStart, stream));
-		hipLaunchKernelGGL(ga_extend_kernel<64>, dim3(slots), dim3(64), 0, stream, L);
+		if (narrow) hipLaunchKernelGGL(ga_extend_kernel<32>, dim3(slots), dim3(64), 0, stream, L);
+		else hipLaunchKernelGGL(ga_extend_kernel<64>, dim3(slots), dim3(64), 0, stream, L);
 		HIP_OK(hipGetLastError());
 		HIP_OK(hipEventRecord(evStop, stream));
 		outs.resize(jobs.size());

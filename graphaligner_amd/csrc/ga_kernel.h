@@ -385,33 +385,40 @@ GA_FN SliceRec slice_at(uint32_t* arena, uint64_t off, uint32_t nNodes, uint32_t
 }
 
 // ---- one column -> stored words -------------------------------------------------------------------
+// 64 finished columns wait in registers, one per lane (v_writelane), and leave as four coalesced
+// stores: VP, VN (8 B), scoreBeforeStart and the packed end score (4 B)  =  24 B per column.
 struct ColumnSink
 {
-	VU accVp, accVn;
-	VI accBefore, accEnd;
+	VI vpLo, vpHi, vnLo, vnHi, before, end;
 	int fill;             // columns waiting in the accumulators
 	uint32_t flushed;     // columns of the slice already written
 };
 
-template <int MAXN>
 GA_FN void flush_columns(ColumnSink& sink, const SliceRec& rec, uint32_t* endCur)
 {
 	if (sink.fill == 0) return;
-	store_lanes(rec.vp + sink.flushed, sink.fill, sink.accVp);
-	store_lanes(rec.vn + sink.flushed, sink.fill, sink.accVn);
-	store_lanes(rec.before + sink.flushed, sink.fill, sink.accBefore);
-	store_lanes(endCur + sink.flushed, sink.fill, sink.accEnd);
+	store_lanes(rec.vp + sink.flushed, sink.fill, make_vu(sink.vpLo, sink.vpHi));
+	store_lanes(rec.vn + sink.flushed, sink.fill, make_vu(sink.vnLo, sink.vnHi));
+	store_lanes(rec.before + sink.flushed, sink.fill, sink.before);
+	store_lanes(endCur + sink.flushed, sink.fill, sink.end);
 	sink.flushed += sink.fill;
 	sink.fill = 0;
 }
 
 // ---- fill one slice: every band node in processing order (GraphAligner.h:2331-2451, 1457-1573) --------
+// Lane r holds T_r = S_r - r for row j+r of the current column (S = cell score).  In that form the
+// column recurrence  S'_r = min(S_r + 1, S_{r-1} + mismatch_r, S'_{r-1} + 1)  becomes
+//     g_r = min(T_r + 1, T_{r-1} - eq_r);   T'_r = min(prefix_min(g)_r, before' + 1)
+// with T_{-1} = before + 1 (before = score at row j-1), i.e. one DPP shift, a handful of VALU
+// ops and a six-step DPP scan per column.  Vertical deltas are T_r - T_{r-1} + 1, so VP / VN are
+// two compares whose 64-bit results are the words the reference keeps (WordSlice.h:194-195).
 // returns status; outputs slice min and the LAST column (in processing order) that attains it
 template <int MAXN>
 GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const uint8_t* rows, uint32_t nRows,
                      uint32_t j, int pn, int cn, int& sliceMin, int& minSlot, uint32_t& minOffset)
 {
 	const VI lane = lane_iota();
+	const VI notLane0 = select(lane == 0, VI(0), VI(1));
 	const VU lowMask = low_mask_through_lane();
 	const VI rowCode = load_lanes(rows + j, W, 0);
 	if (ballot((rowCode & GA_ROW_INVALID) != 0)) return GA_ASSERTION;          // characterMatch default branch (:2104-2106)
@@ -420,7 +427,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 	minSlot = -1;
 	minOffset = 0;
 	ColumnSink sink;
-	sink.accVp = VU(0); sink.accVn = VU(0); sink.accBefore = VI(0); sink.accEnd = VI(0);
+	sink.vpLo = VI(0); sink.vpHi = VI(0); sink.vnLo = VI(0); sink.vnHi = VI(0); sink.before = VI(0); sink.end = VI(0);
 	sink.fill = 0; sink.flushed = 0;
 
 	for (int oi = cn - 1; oi >= 0; oi--)
@@ -432,7 +439,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		const bool inPrev = ps >= 0;
 		const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
 		// columns of one node are written contiguously at cn_colBase; flush what belongs elsewhere
-		if (sink.fill && sink.flushed + sink.fill != ws.cn_colBase[s]) flush_columns<MAXN>(sink, rec, slot.end_cur);
+		if (sink.fill && sink.flushed + sink.fill != ws.cn_colBase[s]) flush_columns(sink, rec, slot.end_cur);
 		if (sink.fill == 0) sink.flushed = ws.cn_colBase[s];
 
 		// ---- the node's graph bases and previous-slice end scores, 64 columns at a time, one lane each ----
@@ -466,28 +473,27 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		VI eqLane = (rowCode >> base) & 1;
 		bool aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);       // "previousEq": raw char ==, not characterMatch (:1503)
 		bool exists0 = inPrev && pend0 == zero0;                                 // scoreBeforeExists from :1989 (scoreEndExists is always true here)
-		VI S;
+		VI T;
 		int before;
 		bool exists;
 		if (!hasIn)
 		{
-			// source node (:1475-1499)
+			// source node (:1475-1499): a vertical run from the cell above
 			if (j == 0 && inPrev)
 			{
-				int firstMis = 1 - read_lane(eqLane, 0);
-				S = lane + (pend0 + firstMis);
+				T = VI(pend0 + 1 - read_lane(eqLane, 0));
 				before = pend0;
 				exists = true;
 			}
 			else if (inPrev)
 			{
-				S = lane + (pend0 + 1);
+				T = VI(pend0 + 1);
 				before = pend0;
 				exists = true;
 			}
 			else
 			{
-				S = lane + (int)(nRows + 1);
+				T = VI((int)(nRows + 1));
 				before = (int)(nRows + 1);
 				exists = false;
 			}
@@ -495,7 +501,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		else
 		{
 			// node start: cell-wise min over the in-neighbours' last columns advanced one step (:1270-1315)
-			VI H = VI(INF);
+			VI G = VI(INF);
 			int calc = INF;
 			for (int e = 0; e < inDeg; e++)
 			{
@@ -503,13 +509,13 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				int cs = find_slot(ws.cn_node, cn, m);
 				int pm = find_slot(ws.pn_node, pn, m);
 				if (cs < 0 && pm < 0) continue;
-				VI left, eq;
+				VI leftT, eq;
 				int leftBefore;
 				bool leftExists;
 				if (cs >= 0)
 				{
 					leftBefore = ws.cn_lastBefore[cs];
-					left = vpopc(ws.cn_lastVP[cs] & lowMask) - vpopc(ws.cn_lastVN[cs] & lowMask) + leftBefore;
+					leftT = vpopc(ws.cn_lastVP[cs] & lowMask) - vpopc(ws.cn_lastVN[cs] & lowMask) + leftBefore - lane;
 					leftExists = ws.cn_lastExists[cs] != 0;
 					eq = eqLane;
 				}
@@ -517,13 +523,13 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				{
 					// neighbour only in the previous band: vertical source column, only row j may match (:1294-1301)
 					leftBefore = ws.pn_lastEnd[pm];
-					left = lane + (leftBefore + 1);
+					leftT = VI(leftBefore + 1);
 					leftExists = true;
 					eq = select(lane == 0, eqLane, VI(0));
 				}
-				if (!(leftExists && pm >= 0)) eq = select(lane == 0, VI(0), eq);      // Eq bit 0 masked (:1358,1360)
-				VI diag = shr1(left, leftBefore);
-				H = vmin(H, vmin(left + 1, diag + 1 - eq));
+				if (!(leftExists && pm >= 0)) eq = eq & notLane0;                       // Eq bit 0 masked (:1358,1360)
+				VI sh = shr1(leftT, leftBefore + 1);
+				G = vmin(G, vmin(leftT + 1, sh - eq));
 				int viaLeft = leftBefore + 1;
 				if (exists0 && pm >= 0)
 				{
@@ -535,8 +541,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			bool reenter = inPrev && calc > pend0;                               // vertical re-entry (:1504-1509)
 			before = reenter ? pend0 : calc;
 			exists = reenter ? true : exists0;
-			VI pm = prefix_min(H - lane);
-			S = vmin(pm + lane, lane + (before + 1));
+			T = vmin(prefix_min(G), VI(before + 1));
 		}
 
 		int nodeMin = INF;
@@ -545,20 +550,20 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		for (uint32_t w = 0;; w++)
 		{
 			// ---- emit column w ----
-			VI up = shr1(S, before);
-			VI delta = S - up;
-			uint64_t vp = ballot(delta == 1);
-			uint64_t vn = ballot(delta == -1);
-			int end = read_lane(S, 63);
-			int end2 = read_lane(S, 62);
-			int packed = (end << 2) | (end - end2 == 1 ? 1 : 0) | (end - end2 == -1 ? 2 : 0);
-			VB here = lane == sink.fill;
-			sink.accVp = select(here, VU(vp), sink.accVp);
-			sink.accVn = select(here, VU(vn), sink.accVn);
-			sink.accBefore = select(here, VI(before), sink.accBefore);
-			sink.accEnd = select(here, VI(packed), sink.accEnd);
+			const VI sh = shr1(T, before + 1);                                   // T of the row above (row j-1: before + 1)
+			const VI d = T - sh;                                                 // vertical delta - 1
+			const uint64_t vp = ballot(d == 0);
+			const uint64_t vn = ballot(d == -2);
+			const int end = read_lane(T, 63) + 63;
+			const int packed = (end << 2) | (int)(vp >> 63) | ((int)(vn >> 63) << 1);
+			sink.vpLo = write_lane(sink.vpLo, (int)(uint32_t)vp, sink.fill);
+			sink.vpHi = write_lane(sink.vpHi, (int)(uint32_t)(vp >> 32), sink.fill);
+			sink.vnLo = write_lane(sink.vnLo, (int)(uint32_t)vn, sink.fill);
+			sink.vnHi = write_lane(sink.vnHi, (int)(uint32_t)(vn >> 32), sink.fill);
+			sink.before = write_lane(sink.before, before, sink.fill);
+			sink.end = write_lane(sink.end, packed, sink.fill);
 			sink.fill++;
-			if (sink.fill == LANES) flush_columns<MAXN>(sink, rec, slot.end_cur);
+			if (sink.fill == LANES) flush_columns(sink, rec, slot.end_cur);
 			nodeMin = end < nodeMin ? end : nodeMin;
 			if (end <= sliceMin) { sliceMin = end; minSlot = s; minOffset = w; }   // last minimum in processing order (:1551-1559, 2410-2418)
 			if (w + 1 == len)
@@ -567,7 +572,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				if (GA_LANE0)
 				{
 					ws.cn_lastVP[s] = vp; ws.cn_lastVN[s] = vn; ws.cn_lastBefore[s] = before; ws.cn_lastExists[s] = exists ? 1 : 0;
-					ws.cn_min[s] = nodeMin; ws.cn_lastEnd[s] = end; ws.cn_lastEnd2[s] = end2;
+					ws.cn_min[s] = nodeMin; ws.cn_lastEnd[s] = end; ws.cn_lastEnd2[s] = end - (int)(vp >> 63) + (int)(vn >> 63);
 				}
 				break;
 			}
@@ -575,15 +580,14 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			const uint32_t wn = w + 1;
 			if ((wn & (LANES - 1)) == 0) loadChunk(wn);
 			base = read_lane(baseChunk, (int)(wn & (LANES - 1)));
-			eqLane = (rowCode >> base) & 1;
 			aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);
-			uint32_t pendRaw = (uint32_t)read_lane(pendChunk, (int)(wn & (LANES - 1)));
-			int pendW = inPrev ? (int)(pendRaw >> 2) : INF;
+			const uint32_t pendRaw = (uint32_t)read_lane(pendChunk, (int)(wn & (LANES - 1)));
+			const int pendW = inPrev ? (int)(pendRaw >> 2) : INF;
 			zero = zero + 1 < pendW ? zero + 1 : pendW;                         // row j-1 chain (:1939-1944)
-			bool existsW = inPrev && pendW == zero;
-			VI eq = exists ? eqLane : select(lane == 0, VI(0), eqLane);
-			VI diag = shr1(S, before);
-			VI H = vmin(S + 1, diag + 1 - eq);
+			const bool existsW = inPrev && pendW == zero;
+			VI eq = (rowCode >> base) & 1;
+			if (!exists) eq = eq & notLane0;                                     // diagonal into row j needs the cell above-left to exist (:1358)
+			const VI G = vmin(T + 1, sh - eq);
 			int calc = before + 1;
 			if (existsW)
 			{
@@ -591,15 +595,14 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				int viaDiag = aboveLeft2 + (aboveEq ? 0 : 1);
 				calc = calc < viaDiag ? calc : viaDiag;
 			}
-			bool reenter = inPrev && calc > pendW;                               // vertical re-entry (:1541-1546)
+			const bool reenter = inPrev && calc > pendW;                         // vertical re-entry (:1541-1546)
 			before = reenter ? pendW : calc;
 			exists = reenter ? true : existsW;
-			VI pmn = prefix_min(H - lane);
-			S = vmin(pmn + lane, lane + (before + 1));
+			T = vmin(prefix_min(G), VI(before + 1));
 			pendLeftRaw = pendRaw;
 		}
 	}
-	flush_columns<MAXN>(sink, rec, slot.end_cur);
+	flush_columns(sink, rec, slot.end_cur);
 	return GA_OK;
 }
 

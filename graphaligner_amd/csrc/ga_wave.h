@@ -66,6 +66,8 @@ inline VI shr1(const VI& x, int fill) { VI r; r.v[0] = fill; for (int i = 1; i <
 inline VI prefix_min(const VI& x) { VI r; int m = INF; for (int i = 0; i < LANES; i++) { m = x.v[i] < m ? x.v[i] : m; r.v[i] = m; } return r; }
 inline uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < LANES; i++) if (c.v[i]) m |= 1ull << i; return m; }
 inline int read_lane(const VI& x, int lane) { return x.v[lane]; }
+inline VI write_lane(VI x, int value, int lane) { x.v[lane] = value; return x; }
+inline VU make_vu(const VI& lo, const VI& hi) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = ((uint64_t)(uint32_t)hi.v[i] << 32) | (uint32_t)lo.v[i]; return r; }
 inline uint64_t read_lane(const VU& x, int lane) { return x.v[lane]; }
 
 // lane i (< count) loads / stores element i; other lanes get `fill` / do nothing
@@ -106,16 +108,23 @@ GA_FN VI shr1(VI x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x13
 // 1 and 3, then row_bcast:31 into rows 2 and 3
 GA_FN VI prefix_min(VI v)
 {
-	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x111, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x112, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x114, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x118, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x142, 0xa, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(INF, v, 0x143, 0xc, 0xf, false));
+	// old = INT_MAX is the identity of signed min, which lets the DPP combiner fold each move into v_min_i32_dpp
+	const int ID = 0x7fffffff;
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x143, 0xc, 0xf, false));
 	return v;
 }
 GA_FN uint64_t ballot(VB c) { return __ballot(c); }
 GA_FN int read_lane(VI x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+// v_writelane_b32: this clang has no builtin for it, so bind the LLVM intrinsic by name (the
+// compiler still schedules it and pads its hazards, unlike inline asm)
+extern "C" __device__ int ga_llvm_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+GA_FN VI write_lane(VI x, int value, int lane) { return ga_llvm_writelane_i32(value, lane, x); }
+GA_FN VU make_vu(VI lo, VI hi) { return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; }
 GA_FN uint64_t read_lane(VU x, int lane)
 {
 	uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
