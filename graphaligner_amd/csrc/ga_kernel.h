@@ -384,34 +384,19 @@ GA_FN SliceRec slice_at(uint32_t* arena, uint64_t off, uint32_t nNodes, uint32_t
 	return r;
 }
 
-// ---- one column -> stored words -------------------------------------------------------------------
-// 64 finished columns wait in registers, one per lane (v_writelane), and leave as four coalesced
-// stores: VP, VN (8 B), scoreBeforeStart and the packed end score (4 B)  =  24 B per column.
-struct ColumnSink
-{
-	VI vpLo, vpHi, vnLo, vnHi, before, end;
-	int fill;             // columns waiting in the accumulators
-	uint32_t flushed;     // columns of the slice already written
-};
-
-GA_FN void flush_columns(ColumnSink& sink, const SliceRec& rec, uint32_t* endCur)
-{
-	if (sink.fill == 0) return;
-	store_lanes(rec.vp + sink.flushed, sink.fill, make_vu(sink.vpLo, sink.vpHi));
-	store_lanes(rec.vn + sink.flushed, sink.fill, make_vu(sink.vnLo, sink.vnHi));
-	store_lanes(rec.before + sink.flushed, sink.fill, sink.before);
-	store_lanes(endCur + sink.flushed, sink.fill, sink.end);
-	sink.flushed += sink.fill;
-	sink.fill = 0;
-}
-
 // ---- fill one slice: every band node in processing order (GraphAligner.h:2331-2451, 1457-1573) --------
-// Lane r holds T_r = S_r - r for row j+r of the current column (S = cell score).  In that form the
-// column recurrence  S'_r = min(S_r + 1, S_{r-1} + mismatch_r, S'_{r-1} + 1)  becomes
-//     g_r = min(T_r + 1, T_{r-1} - eq_r);   T'_r = min(prefix_min(g)_r, before' + 1)
-// with T_{-1} = before + 1 (before = score at row j-1), i.e. one DPP shift, a handful of VALU
-// ops and a six-step DPP scan per column.  Vertical deltas are T_r - T_{r-1} + 1, so VP / VN are
-// two compares whose 64-bit results are the words the reference keeps (WordSlice.h:194-195).
+// Two lane layouts alternate:
+//  * lanes = the 64 read rows.  Lane r holds T_r = S_r - r for row j+r of the current column
+//    (S = cell score).  The column recurrence  S'_r = min(S_r + 1, S_{r-1} + mismatch_r, S'_{r-1} + 1)
+//    becomes   g_r = min(T_r + 1, T_{r-1} - eq_r);   T'_r = min(prefix_min(g)_r, before' + 1)
+//    with T_{-1} = before + 1 (before = score at row j-1): one DPP shift, a few VALU ops and a
+//    six-step DPP scan per column.  Vertical deltas are T_r - T_{r-1} + 1, so VP / VN are two
+//    compares whose 64-bit results are the words the reference keeps (WordSlice.h:194-195).
+//  * lanes = up to 64 consecutive COLUMNS of the node (a chunk).  Everything the reference derives
+//    column by column for the virtual row j-1 -- forceComponentZeroRow's chain (:1939-1944),
+//    scoreBeforeStart / scoreBeforeExists of getNextSlice (:1358-1370) and the vertical re-entry
+//    test (:1541-1546) -- is a min-plus recurrence along the node and is evaluated for the whole
+//    chunk with the same DPP scan, then read back one lane per column.
 // returns status; outputs slice min and the LAST column (in processing order) that attains it
 template <int MAXN>
 GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const uint8_t* rows, uint32_t nRows,
@@ -426,9 +411,6 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 	sliceMin = INF;
 	minSlot = -1;
 	minOffset = 0;
-	ColumnSink sink;
-	sink.vpLo = VI(0); sink.vpHi = VI(0); sink.vnLo = VI(0); sink.vnHi = VI(0); sink.before = VI(0); sink.end = VI(0);
-	sink.fill = 0; sink.flushed = 0;
 
 	for (int oi = cn - 1; oi >= 0; oi--)
 	{
@@ -438,25 +420,20 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		const int ps = ws.cn_prev[s];
 		const bool inPrev = ps >= 0;
 		const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
-		// columns of one node are written contiguously at cn_colBase; flush what belongs elsewhere
-		if (sink.fill && sink.flushed + sink.fill != ws.cn_colBase[s]) flush_columns(sink, rec, slot.end_cur);
-		if (sink.fill == 0) sink.flushed = ws.cn_colBase[s];
-
-		// ---- the node's graph bases and previous-slice end scores, 64 columns at a time, one lane each ----
+		const uint32_t outBase = ws.cn_colBase[s];
 		const uint32_t bit0 = (uint32_t)(firstCol & 15);
 		const uint32_t* seqWords = g.seq2 + (firstCol >> 4);
-		VI baseChunk, pendChunk;
-		auto loadChunk = [&](uint32_t w0) {
-			VI at = lane + (int)(bit0 + w0);
-			baseChunk = (gather(seqWords, at >> 4) >> ((at & 15) << 1)) & 3;
-			pendChunk = inPrev ? load_lanes(pend + w0, (int)(len - w0), 0) : VI(0);
-		};
-		loadChunk(0);
+		const bool aboveAlways = j == 0 && inPrev;                              // "previousEq" (:1503): raw char ==, not characterMatch
+
+		// ---- first chunk's operands: graph bases and previous-slice end words, one column per lane ----
+		VI at = lane + (int)bit0;
+		VI baseV = (gather(seqWords, at >> 4) >> ((at & 15) << 1)) & 3;
+		VI pendRawV = inPrev ? load_lanes(pend, (int)len, 0) : VI(0);
 
 		// --- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ---
 		const int inDeg = in_degree(g, ws, s);
-		int pend0raw = read_lane(pendChunk, 0);
-		int pend0 = inPrev ? (pend0raw >> 2) : INF;
+		const int pend0raw = read_lane(pendRawV, 0);
+		const int pend0 = inPrev ? (pend0raw >> 2) : INF;
 		int zero0 = pend0;
 		bool hasIn = false;
 		for (int e = 0; e < inDeg; e++)
@@ -469,34 +446,19 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			if (cs >= 0) zero0 = zero0 < ws.cn_lastBefore[cs] + 1 ? zero0 : ws.cn_lastBefore[cs] + 1;
 			if (pm >= 0) zero0 = zero0 < ws.pn_lastEnd[pm] + 1 ? zero0 : ws.pn_lastEnd[pm] + 1;
 		}
-		int base = read_lane(baseChunk, 0);
-		VI eqLane = (rowCode >> base) & 1;
-		bool aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);       // "previousEq": raw char ==, not characterMatch (:1503)
-		bool exists0 = inPrev && pend0 == zero0;                                 // scoreBeforeExists from :1989 (scoreEndExists is always true here)
+		const int base0 = read_lane(baseV, 0);
+		const VI eqLane0 = bit_extract(rowCode, base0);
+		const bool aboveEq0 = aboveAlways || (j > 0 && rawAbove == base0);
+		const bool exists0 = inPrev && pend0 == zero0;                           // scoreBeforeExists from :1989 (scoreEndExists is always true here)
 		VI T;
-		int before;
-		bool exists;
+		int before0;
+		bool existsFirst;
 		if (!hasIn)
 		{
 			// source node (:1475-1499): a vertical run from the cell above
-			if (j == 0 && inPrev)
-			{
-				T = VI(pend0 + 1 - read_lane(eqLane, 0));
-				before = pend0;
-				exists = true;
-			}
-			else if (inPrev)
-			{
-				T = VI(pend0 + 1);
-				before = pend0;
-				exists = true;
-			}
-			else
-			{
-				T = VI((int)(nRows + 1));
-				before = (int)(nRows + 1);
-				exists = false;
-			}
+			if (j == 0 && inPrev) { T = VI(pend0 + 1 - read_lane(eqLane0, 0)); before0 = pend0; existsFirst = true; }
+			else if (inPrev) { T = VI(pend0 + 1); before0 = pend0; existsFirst = true; }
+			else { T = VI((int)(nRows + 1)); before0 = (int)(nRows + 1); existsFirst = false; }
 		}
 		else
 		{
@@ -517,7 +479,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 					leftBefore = ws.cn_lastBefore[cs];
 					leftT = vpopc(ws.cn_lastVP[cs] & lowMask) - vpopc(ws.cn_lastVN[cs] & lowMask) + leftBefore - lane;
 					leftExists = ws.cn_lastExists[cs] != 0;
-					eq = eqLane;
+					eq = eqLane0;
 				}
 				else
 				{
@@ -525,84 +487,115 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 					leftBefore = ws.pn_lastEnd[pm];
 					leftT = VI(leftBefore + 1);
 					leftExists = true;
-					eq = select(lane == 0, eqLane, VI(0));
+					eq = select(lane == 0, eqLane0, VI(0));
 				}
 				if (!(leftExists && pm >= 0)) eq = eq & notLane0;                       // Eq bit 0 masked (:1358,1360)
-				VI sh = shr1(leftT, leftBefore + 1);
-				G = vmin(G, vmin(leftT + 1, sh - eq));
+				VI shl = shr1(leftT, leftBefore + 1);
+				G = vmin(G, vmin(leftT + 1, shl - eq));
 				int viaLeft = leftBefore + 1;
 				if (exists0 && pm >= 0)
 				{
-					int viaDiag = ws.pn_lastEnd2[pm] + (aboveEq ? 0 : 1);
+					int viaDiag = ws.pn_lastEnd2[pm] + (aboveEq0 ? 0 : 1);
 					viaLeft = viaLeft < viaDiag ? viaLeft : viaDiag;
 				}
 				calc = calc < viaLeft ? calc : viaLeft;
 			}
 			bool reenter = inPrev && calc > pend0;                               // vertical re-entry (:1504-1509)
-			before = reenter ? pend0 : calc;
-			exists = reenter ? true : exists0;
-			T = vmin(prefix_min(G), VI(before + 1));
+			before0 = reenter ? pend0 : calc;
+			existsFirst = reenter ? true : exists0;
+			T = vmin(prefix_min(G), VI(before0 + 1));
 		}
 
 		int nodeMin = INF;
-		int zero = zero0;
-		uint32_t pendLeftRaw = (uint32_t)pend0raw;                              // packed end word of the column to the left, previous slice
-		for (uint32_t w = 0;; w++)
+		int carryZero = INF, carryBefore = INF, carryAbove2 = 0;
+		bool carryExists = false;
+		VI sh = VI(0);
+		uint64_t vp = 0, vn = 0;
+		int lastBefore = before0, lastEndT = 0, lastZero = zero0;
+		bool lastExists = existsFirst;
+		for (uint32_t w0 = 0; w0 < len; w0 += LANES)
 		{
-			// ---- emit column w ----
-			const VI sh = shr1(T, before + 1);                                   // T of the row above (row j-1: before + 1)
-			const VI d = T - sh;                                                 // vertical delta - 1
-			const uint64_t vp = ballot(d == 0);
-			const uint64_t vn = ballot(d == -2);
-			const int end = read_lane(T, 63) + 63;
-			const int packed = (end << 2) | (int)(vp >> 63) | ((int)(vn >> 63) << 1);
-			sink.vpLo = write_lane(sink.vpLo, (int)(uint32_t)vp, sink.fill);
-			sink.vpHi = write_lane(sink.vpHi, (int)(uint32_t)(vp >> 32), sink.fill);
-			sink.vnLo = write_lane(sink.vnLo, (int)(uint32_t)vn, sink.fill);
-			sink.vnHi = write_lane(sink.vnHi, (int)(uint32_t)(vn >> 32), sink.fill);
-			sink.before = write_lane(sink.before, before, sink.fill);
-			sink.end = write_lane(sink.end, packed, sink.fill);
-			sink.fill++;
-			if (sink.fill == LANES) flush_columns(sink, rec, slot.end_cur);
-			nodeMin = end < nodeMin ? end : nodeMin;
-			if (end <= sliceMin) { sliceMin = end; minSlot = s; minOffset = w; }   // last minimum in processing order (:1551-1559, 2410-2418)
-			if (w + 1 == len)
+			const int n = (int)(len - w0 < (uint32_t)LANES ? len - w0 : (uint32_t)LANES);
+			const bool first = w0 == 0;
+			if (!first)
 			{
-				if (before != zero) return GA_ASSERTION;                         // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
-				if (GA_LANE0)
+				at = lane + (int)(bit0 + w0);
+				baseV = (gather(seqWords, at >> 4) >> ((at & 15) << 1)) & 3;
+				pendRawV = inPrev ? load_lanes(pend + w0, n, 0) : VI(0);
+			}
+			// ---- the row j-1 bookkeeping of the whole chunk, lanes = columns ----
+			const VB live = lane < n;
+			const VI pendV = inPrev ? select(live, pendRawV >> 2, VI(INF)) : VI(INF);
+			const VI above2own = (pendRawV >> 2) - (pendRawV & 1) + ((pendRawV >> 1) & 1);      // score at row j-2 of the own column
+			const VI above2left = shr1(above2own, carryAbove2);
+			const VI aboveEqV = aboveAlways ? VI(1) : (j > 0 ? select(baseV == rawAbove, VI(1), VI(0)) : VI(0));
+			// zero row (:1939-1944): zero[w] = min(zero[w-1] + 1, pend[w])
+			const VI zeroIn = first ? select(lane == 0, VI(zero0), pendV) : pendV;
+			const VI zeroV = vmin(prefix_min(zeroIn - lane) + lane, first ? VI(INF) : lane + (carryZero + 1));
+			const VI existsWV = inPrev ? select(pendV == zeroV, VI(1), VI(0)) : VI(0);
+			const VI viaDiagV = select(existsWV != 0, above2left + 1 - aboveEqV, VI(INF));   // :1369
+			// scoreBeforeStart (:1361-1370, then re-entry :1541-1546): before[w] = min(before[w-1] + 1, viaDiag[w], pend[w])
+			const VI cIn = first ? select(lane == 0, VI(before0), vmin(pendV, viaDiagV)) : vmin(pendV, viaDiagV);
+			const VI beforeV = vmin(prefix_min(cIn - lane) + lane, first ? VI(INF) : lane + (carryBefore + 1));
+			const VI beforeLeft = shr1(beforeV, carryBefore);
+			const VI calcV = vmin(beforeLeft + 1, viaDiagV);
+			const VB reenterV = (calcV > pendV) && inPrev;
+			uint64_t existsMask = ballot(reenterV) | ballot(existsWV != 0);
+			if (first) existsMask = (existsMask & ~1ull) | (existsFirst ? 1ull : 0ull);
+
+			VI accVpLo = VI(0), accVpHi = VI(0), accVnLo = VI(0), accVnHi = VI(0), accEnd = VI(0);
+			for (int c = 0; c < n; c++)
+			{
+				const int before = read_lane(beforeV, c);
+				if (!(first && c == 0))
 				{
-					ws.cn_lastVP[s] = vp; ws.cn_lastVN[s] = vn; ws.cn_lastBefore[s] = before; ws.cn_lastExists[s] = exists ? 1 : 0;
-					ws.cn_min[s] = nodeMin; ws.cn_lastEnd[s] = end; ws.cn_lastEnd2[s] = end - (int)(vp >> 63) + (int)(vn >> 63);
+					// ---- column w0+c from the column to its left (calculateNode :1533-1546, getNextSlice :1349-1427) ----
+					const bool leftExists = c > 0 ? ((existsMask >> (c - 1)) & 1) != 0 : carryExists;
+					const int base = read_lane(baseV, c);
+					VI eq = bit_extract(rowCode, base) & (notLane0 | leftExists);   // diagonal into row j needs the cell above-left to exist (:1358)
+					const VI G = vmin(T + 1, sh - eq);
+					T = vmin(prefix_min(G), VI(before + 1));
 				}
-				break;
+				// ---- emit ----
+				sh = shr1(T, before + 1);                                        // T of the row above (row j-1: before + 1)
+				const VI d = T - sh;                                             // vertical delta - 1
+				vp = ballot(d == 0);
+				vn = ballot(d == -2);
+				lastEndT = read_lane(T, 63);
+				accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, c);
+				accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), c);
+				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, c);
+				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), c);
+				accEnd = write_lane(accEnd, lastEndT, c);
 			}
-			// ---- column w+1 from column w (calculateNode inner loop :1533-1546, getNextSlice :1349-1427) ----
-			const uint32_t wn = w + 1;
-			if ((wn & (LANES - 1)) == 0) loadChunk(wn);
-			base = read_lane(baseChunk, (int)(wn & (LANES - 1)));
-			aboveEq = (j == 0 && inPrev) || (j > 0 && rawAbove == base);
-			const uint32_t pendRaw = (uint32_t)read_lane(pendChunk, (int)(wn & (LANES - 1)));
-			const int pendW = inPrev ? (int)(pendRaw >> 2) : INF;
-			zero = zero + 1 < pendW ? zero + 1 : pendW;                         // row j-1 chain (:1939-1944)
-			const bool existsW = inPrev && pendW == zero;
-			VI eq = (rowCode >> base) & 1;
-			if (!exists) eq = eq & notLane0;                                     // diagonal into row j needs the cell above-left to exist (:1358)
-			const VI G = vmin(T + 1, sh - eq);
-			int calc = before + 1;
-			if (existsW)
-			{
-				int aboveLeft2 = (int)(pendLeftRaw >> 2) - (int)(pendLeftRaw & 1) + (int)((pendLeftRaw >> 1) & 1);
-				int viaDiag = aboveLeft2 + (aboveEq ? 0 : 1);
-				calc = calc < viaDiag ? calc : viaDiag;
-			}
-			const bool reenter = inPrev && calc > pendW;                         // vertical re-entry (:1541-1546)
-			before = reenter ? pendW : calc;
-			exists = reenter ? true : existsW;
-			T = vmin(prefix_min(G), VI(before + 1));
-			pendLeftRaw = pendRaw;
+			// ---- the chunk leaves as four coalesced stores (VP, VN 8 B; before, packed end 4 B) ----
+			const VI endV = accEnd + 63;
+			const VI packedV = (endV << 2) | ((accVpHi >> 31) & 1) | (((accVnHi >> 31) & 1) << 1);
+			store_lanes(rec.vp + outBase + w0, n, make_vu(accVpLo, accVpHi));
+			store_lanes(rec.vn + outBase + w0, n, make_vu(accVnLo, accVnHi));
+			store_lanes(rec.before + outBase + w0, n, beforeV);
+			store_lanes(slot.end_cur + outBase + w0, n, packedV);
+			// minimum end score of the chunk and the LAST column attaining it (:1551-1559, 2410-2418)
+			const VI endLive = select(live, endV, VI(INF));
+			const int chunkMin = read_lane(prefix_min(endLive), LANES - 1);
+			const uint64_t atMin = ballot(endLive == chunkMin);
+			nodeMin = chunkMin < nodeMin ? chunkMin : nodeMin;
+			if (chunkMin <= sliceMin) { sliceMin = chunkMin; minSlot = s; minOffset = w0 + (uint32_t)(63 - __builtin_clzll(atMin)); }
+			// carries into the next chunk
+			carryZero = read_lane(zeroV, n - 1);
+			carryBefore = read_lane(beforeV, n - 1);
+			carryAbove2 = read_lane(above2own, n - 1);
+			carryExists = ((existsMask >> (n - 1)) & 1) != 0;
+			lastBefore = carryBefore; lastZero = carryZero; lastExists = carryExists;
+		}
+		if (lastBefore != lastZero) return GA_ASSERTION;                         // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
+		if (GA_LANE0)
+		{
+			const int end = lastEndT + 63;
+			ws.cn_lastVP[s] = vp; ws.cn_lastVN[s] = vn; ws.cn_lastBefore[s] = lastBefore; ws.cn_lastExists[s] = lastExists ? 1 : 0;
+			ws.cn_min[s] = nodeMin; ws.cn_lastEnd[s] = end; ws.cn_lastEnd2[s] = end - (int)(vp >> 63) + (int)(vn >> 63);
 		}
 	}
-	flush_columns(sink, rec, slot.end_cur);
 	return GA_OK;
 }
 
@@ -841,6 +834,38 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			const VI valR = cw.before + vpopc(maskR & cw.vp) - vpopc(maskR & cw.vn);
 			const int here = read_lane(valR, rel);
 			if (row == 0 && node == job.seed_node && (here == 0 || here == 1)) { row = 0xffffffffu; continue; }   // free start (:500)
+			// ---- a run of diagonal steps inside the window, all at once ----
+			// Lane L looks at the diagonal cell (column L, row L + r - rel).  A step from column L+1
+			// to L is diagonal iff the horizontal move is not taken (:541-546) and the diagonal cell
+			// has the matching score (:556-571); the run is the stretch of such lanes below `rel`.
+			if (rel >= 1 && r >= 1)
+			{
+				const VI rho = lane + (r - rel);
+				const VU mA = mask_low_bits(rho + 1), mB = mask_low_bits(rho + 2);
+				const VI A = cw.before + vpopc(cw.vp & mA) - vpopc(cw.vn & mA);
+				const VI B = cw.before + vpopc(cw.vp & mB) - vpopc(cw.vn & mB);
+				const VI mOwn = (lane_gather(rowv, rho) >> winBases) & 1;
+				const VI hereSrc = shl1(A, 0), mSrc = shl1(mOwn, 0);
+				const uint64_t cond = ballot(B > hereSrc - 1) & ballot(A == hereSrc - 1 + mSrc) & ballot((lane < rel) && (rho > -1));
+				const uint64_t broken = ~(cond << (64 - rel));
+				int run = broken == 0 ? 64 : __builtin_clzll(broken);
+				run = run < rel ? run : rel;
+				if (run >= 2)
+				{
+					// positions 1 .. run-1 of the run go out in one scatter; position `run` is recorded by the next iteration
+					if (len + (uint32_t)run > L.trace_cap) { status = GA_CAP_TRACE; break; }
+					const VB mine = (lane < rel) && (lane > rel - run);
+					const VI at3 = (VI((int)len) + (rel - 1) - lane) * 3;
+					uint32_t* trw = (uint32_t*)tr;
+					scatter(trw, at3, VI((int)node), mine);
+					scatter(trw, at3 + 1, lane + cw.lo, mine);
+					scatter(trw, at3 + 2, rho + (int)(sIdx * W), mine);
+					len += (uint32_t)(run - 1);
+					offset -= (uint32_t)run;
+					row -= (uint32_t)run;
+					continue;
+				}
+			}
 			const int rowCode = read_lane(rowv, r);
 			const int base = read_lane(winBases, rel);
 			const bool match = (rowCode >> base) & 1;

@@ -40,7 +40,7 @@ struct VU
 	inline VI operator OP(const VI& a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
 	inline VI operator OP(const VI& a, int b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] OP b; return r; } \
 	inline VI operator OP(int a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a OP b.v[i]; return r; }
-GAW_BIN(+) GAW_BIN(-) GAW_BIN(&) GAW_BIN(|) GAW_BIN(>>) GAW_BIN(<<)
+GAW_BIN(+) GAW_BIN(-) GAW_BIN(&) GAW_BIN(|) GAW_BIN(>>) GAW_BIN(<<) GAW_BIN(*)
 #undef GAW_BIN
 #define GAW_CMP(OP) \
 	inline VB operator OP(const VI& a, const VI& b) { VB r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] OP b.v[i]; return r; } \
@@ -51,11 +51,20 @@ inline VB operator&&(const VB& a, const VB& b) { VB r; for (int i = 0; i < LANES
 inline VB operator&&(const VB& a, bool b) { VB r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] && b; return r; }
 inline VU operator&(uint64_t a, const VU& b) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = a & b.v[i]; return r; }
 
+inline VU operator&(const VU& a, const VU& b) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] & b.v[i]; return r; }
+// lane i receives lane i+1; lane 63 receives `fill`
+inline VI shl1(const VI& x, int fill) { VI r; r.v[LANES - 1] = fill; for (int i = 0; i + 1 < LANES; i++) r.v[i] = x.v[i + 1]; return r; }
+// lane i receives x[idx_i] (idx taken modulo 64)
+inline VI lane_gather(const VI& x, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = x.v[idx.v[i] & 63]; return r; }
+// per-lane word with the low `nbits` bits set (nbits <= 0 -> 0, >= 64 -> all)
+inline VU mask_low_bits(const VI& nbits) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = nbits.v[i] <= 0 ? 0ull : nbits.v[i] >= 64 ? ~0ull : ((1ull << nbits.v[i]) - 1); return r; }
 inline VI lane_iota() { VI r; for (int i = 0; i < LANES; i++) r.v[i] = i; return r; }
 inline VI vmin(const VI& a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VI vmin(const VI& a, int b) { return vmin(a, VI(b)); }
 inline VI select(const VB& c, const VI& a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VU select(const VB& c, const VU& a, const VU& b) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+inline VI bit_extract(const VI& x, int bit) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (x.v[i] >> bit) & 1; return r; }
+inline VI operator|(const VI& a, bool b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] | (b ? 1 : 0); return r; }
 inline VI vpopc(const VU& a) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = __builtin_popcountll(a.v[i]); return r; }
 // bits 0..lane of a 64-bit word
 inline VU low_mask_through_lane() { VU r; for (int i = 0; i < LANES; i++) r.v[i] = i == 63 ? ~0ull : ((2ull << i) - 1); return r; }
@@ -95,10 +104,15 @@ typedef bool VB;
 typedef int VI;
 typedef uint64_t VU;
 
+// v_mov_b32 dpp wave_shl:1 -- lane 63 has no source lane and keeps `fill`
+GA_FN VI shl1(VI x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
+GA_FN VI lane_gather(VI x, VI idx) { return __builtin_amdgcn_ds_bpermute((idx & 63) << 2, x); }
+GA_FN VU mask_low_bits(VI nbits) { return nbits <= 0 ? 0ull : nbits >= 64 ? ~0ull : ((1ull << nbits) - 1); }
 GA_FN VI lane_iota() { return (int)threadIdx.x; }
 GA_FN VI vmin(VI a, VI b) { return a < b ? a : b; }
 GA_FN VI select(VB c, VI a, VI b) { return c ? a : b; }
 GA_FN VU select(VB c, VU a, VU b) { return c ? a : b; }
+GA_FN VI bit_extract(VI x, int bit) { return (int)__builtin_amdgcn_ubfe((unsigned)x, (unsigned)bit, 1u); }
 GA_FN VI vpopc(VU a) { return __builtin_popcountll(a); }
 GA_FN VU low_mask_through_lane() { return threadIdx.x == 63 ? ~0ull : ((2ull << threadIdx.x) - 1); }
 
