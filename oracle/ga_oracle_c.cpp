@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <queue>
 #include <thread>
 
 using namespace gao;
@@ -146,6 +147,22 @@ int gao_frozen_order(const int64_t* nodes, int n, int64_t graphNodes, int64_t* o
 	auto o = frozenIterationOrder(v, (size_t)graphNodes);
 	for (size_t i = 0; i < o.size(); i++) out[i] = (int64_t)o[i];
 	return (int)o.size();
+}
+// std::priority_queue<.., std::greater<>> comparing priorities only (GraphAligner.h:1094-1115):
+// ops with prio >= 0 push (node, prio), prio < 0 pop; whatever is left is popped at the end.
+// The pop order among equal priorities is what the device-side heap has to reproduce.
+int gao_pq_order(const uint32_t* nodes, const int32_t* prios, int nOps, uint32_t* popped)
+{
+	struct Item { uint32_t node; int prio; bool operator>(const Item& o) const { return prio > o.prio; } };
+	std::priority_queue<Item, std::vector<Item>, std::greater<Item>> q;
+	int k = 0;
+	for (int i = 0; i < nOps; i++)
+	{
+		if (prios[i] >= 0) q.push(Item{nodes[i], prios[i]});
+		else if (!q.empty()) { popped[k++] = q.top().node; q.pop(); }
+	}
+	while (!q.empty()) { popped[k++] = q.top().node; q.pop(); }
+	return k;
 }
 int gao_char_match(int readChar, int graphChar)
 {
