@@ -46,3 +46,8 @@ def test_gfa_loader_matches_node_edge_api():
 
 def test_full_size_properties():
     cases.case_full_size_properties()
+
+
+def test_golden_vectors():
+    import test_oracle_golden as tg
+    tg.run_device_on_golden(None)
