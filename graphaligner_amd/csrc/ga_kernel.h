@@ -26,6 +26,9 @@ using namespace gaw;
 constexpr int W = 64;
 constexpr uint32_t kCutoff = 200000;         // GraphAlignerCommon.h:10
 constexpr int kSliceHdrWords = 6;
+#ifndef GA_ABLATE
+#define GA_ABLATE 0          // timing experiments only (results are wrong when non-zero)
+#endif
 constexpr int kNbr = 4;                      // neighbours per band node cached in LDS
 
 template <int MAXN> struct Limits
@@ -399,19 +402,32 @@ GA_FN SliceRec slice_at(uint32_t* arena, uint64_t off, uint32_t nNodes, uint32_t
 //    chunk with the same DPP scan, then read back one lane per column.
 // returns status; outputs slice min and the LAST column (in processing order) that attains it
 template <int MAXN>
-GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const uint8_t* rows, uint32_t nRows,
+GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const VI rowCode, const int rowAboveCode, uint32_t nRows,
                      uint32_t j, int pn, int cn, int& sliceMin, int& minSlot, uint32_t& minOffset)
 {
 	const VI lane = lane_iota();
 	const VI notLane0 = select(lane == 0, VI(0), VI(1));
 	const VU lowMask = low_mask_through_lane();
-	const VI rowCode = load_lanes(rows + j, W, 0);
+	// match bits of the row for bases 0..3, and in bits 4..7 the same with lane 0 forced to "no match"
+	const VI rowCode2 = (rowCode & 15) | (((rowCode & 15) * notLane0) << 4);
 	if (ballot((rowCode & GA_ROW_INVALID) != 0)) return GA_ASSERTION;          // characterMatch default branch (:2104-2106)
-	const int rawAbove = j > 0 ? (rows[j - 1] >> 4) & 7 : 7;                     // read char of row j-1, exact-compare code
+	const int rawAbove = j > 0 ? (rowAboveCode >> 4) & 7 : 7;                    // read char of row j-1, exact-compare code
 	sliceMin = INF;
 	minSlot = -1;
 	minOffset = 0;
 
+	// operands of a node's first chunk (graph bases, previous-slice end words: one column per lane) are
+	// requested one node ahead, so their HBM/L2 latency hides behind the previous node's columns
+	VI nextBaseV = VI(0), nextPendV = VI(0);
+	auto requestNode = [&](int oiNext) {
+		const int sn = ws.post[oiNext];
+		const uint64_t fc = ((uint64_t)ws.cn_startHi[sn] << 32) | ws.cn_startLo[sn];
+		const int psn = ws.cn_prev[sn];
+		VI atn = lane + (int)(fc & 15);
+		nextBaseV = (gather(g.seq2 + (fc >> 4), atn >> 4) >> ((atn & 15) << 1)) & 3;
+		nextPendV = psn >= 0 ? load_lanes(slot.end_prev + ws.pn_colBase[psn], (int)ws.cn_len[sn], 0) : VI(0);
+	};
+	if (cn > 0) requestNode(cn - 1);
 	for (int oi = cn - 1; oi >= 0; oi--)
 	{
 		const int s = ws.post[oi];
@@ -425,10 +441,10 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		const uint32_t* seqWords = g.seq2 + (firstCol >> 4);
 		const bool aboveAlways = j == 0 && inPrev;                              // "previousEq" (:1503): raw char ==, not characterMatch
 
-		// ---- first chunk's operands: graph bases and previous-slice end words, one column per lane ----
-		VI at = lane + (int)bit0;
-		VI baseV = (gather(seqWords, at >> 4) >> ((at & 15) << 1)) & 3;
-		VI pendRawV = inPrev ? load_lanes(pend, (int)len, 0) : VI(0);
+		VI at;
+		VI baseV = nextBaseV;
+		VI pendRawV = nextPendV;
+		if (oi > 0) requestNode(oi - 1);
 
 		// --- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ---
 		const int inDeg = in_degree(g, ws, s);
@@ -509,9 +525,9 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		int nodeMin = INF;
 		int carryZero = INF, carryBefore = INF, carryAbove2 = 0;
 		bool carryExists = false;
-		VI sh = VI(0);
+		VI sh = VI(0), Tp1 = VI(0);
 		uint64_t vp = 0, vn = 0;
-		int lastBefore = before0, lastEndT = 0, lastZero = zero0;
+		int lastBefore = before0, lastEnd = 0, lastZero = zero0;
 		bool lastExists = existsFirst;
 		for (uint32_t w0 = 0; w0 < len; w0 += LANES)
 		{
@@ -540,41 +556,68 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			const VI beforeLeft = shr1(beforeV, carryBefore);
 			const VI calcV = vmin(beforeLeft + 1, viaDiagV);
 			const VB reenterV = (calcV > pendV) && inPrev;
-			uint64_t existsMask = ballot(reenterV) | ballot(existsWV != 0);
-			if (first) existsMask = (existsMask & ~1ull) | (existsFirst ? 1ull : 0ull);
+			VI existsV = select(reenterV, VI(1), existsWV);                    // final scoreBeforeExists of every column of the chunk
+			if (first) existsV = select(lane == 0, VI(existsFirst ? 1 : 0), existsV);
+			// One scalar per column steers the inner loop: the bit offset into rowCode2 = graph base, +4 when the
+			// column to the left has no existing cell above it (then lane 0 must not see a match, :1358).
+			const VI offV = baseV + select(shr1(existsV, carryExists ? 1 : 0) != 0, VI(0), VI(4));
+			const VI beforeP1V = beforeV + 1;
 
-			VI accVpLo = VI(0), accVpHi = VI(0), accVnLo = VI(0), accVnHi = VI(0), accEnd = VI(0);
-			for (int c = 0; c < n; c++)
+			VI accVpLo = VI(0), accVpHi = VI(0), accVnLo = VI(0), accVnHi = VI(0);
+			// The column loop is software-pipelined by one column: while the DPP scan of column c runs (a
+			// chain of dependent instructions), the words of column c-1 are formed and put away.
+			int c = 0;
+			if (!first)
 			{
-				const int before = read_lane(beforeV, c);
-				if (!(first && c == 0))
-				{
-					// ---- column w0+c from the column to its left (calculateNode :1533-1546, getNextSlice :1349-1427) ----
-					const bool leftExists = c > 0 ? ((existsMask >> (c - 1)) & 1) != 0 : carryExists;
-					const int base = read_lane(baseV, c);
-					VI eq = bit_extract(rowCode, base) & (notLane0 | leftExists);   // diagonal into row j needs the cell above-left to exist (:1358)
-					const VI G = vmin(T + 1, sh - eq);
-					T = vmin(prefix_min(G), VI(before + 1));
-				}
-				// ---- emit ----
-				sh = shr1(T, before + 1);                                        // T of the row above (row j-1: before + 1)
-				const VI d = T - sh;                                             // vertical delta - 1
-				vp = ballot(d == 0);
-				vn = ballot(d == -2);
-				lastEndT = read_lane(T, 63);
-				accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, c);
-				accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), c);
-				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, c);
-				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), c);
-				accEnd = write_lane(accEnd, lastEndT, c);
+				// first column of a later chunk: step from the last column of the previous chunk
+				const int bp1 = read_lane(beforeP1V, 0);
+				const VI eq = bit_extract(rowCode2, read_lane(offV, 0));
+				T = vmin(prefix_min(vmin(Tp1, sh - eq)), VI(bp1));
 			}
+			{
+				const int bp1 = read_lane(beforeP1V, 0);
+				sh = shr1(T, bp1);
+				Tp1 = T + 1;
+			}
+			// the two per-column scalars (T of the virtual row j-1, bit offset into rowCode2) are fetched one
+			// column ahead with a uniform ds_bpermute: they arrive in VGPRs without spending VALU cycles
+			VI bp1Next = lane_broadcast(beforeP1V, 1), offNext = lane_broadcast(offV, 1);
+			for (c = 1; c < n; c++)
+			{
+				// ---- column w0+c from the column to its left (calculateNode :1533-1546, getNextSlice :1349-1427) ----
+				const VI bp1v = bp1Next, offv = offNext;
+				bp1Next = lane_broadcast(beforeP1V, c + 1);
+				offNext = lane_broadcast(offV, c + 1);
+				const VI eq = bit_extract_v(rowCode2, offv);
+				const VI G = vmin(Tp1, sh - eq);
+				// ---- emit column c-1: vertical deltas against the row above (row j-1 holds T = before + 1) ----
+				vp = ballot(T == sh);                                            // delta +1
+				vn = ballot(Tp1 < sh);                                           // delta -1
+#if GA_ABLATE != 1
+				accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, c - 1);
+				accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), c - 1);
+				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, c - 1);
+				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), c - 1);
+#endif
+				T = vmin(prefix_min(G), bp1v);
+				sh = shr1v(T, bp1v);
+				Tp1 = T + 1;
+			}
+			vp = ballot(T == sh);
+			vn = ballot(Tp1 < sh);
+			accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, n - 1);
+			accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), n - 1);
+			accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, n - 1);
+			accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), n - 1);
 			// ---- the chunk leaves as four coalesced stores (VP, VN 8 B; before, packed end 4 B) ----
-			const VI endV = accEnd + 63;
+			const VU vpV = make_vu(accVpLo, accVpHi), vnV = make_vu(accVnLo, accVnHi);
+			const VI endV = beforeV + vpopc(vpV) - vpopc(vnV);                   // scoreEnd = scoreBeforeStart + popcount(VP) - popcount(VN)
 			const VI packedV = (endV << 2) | ((accVpHi >> 31) & 1) | (((accVnHi >> 31) & 1) << 1);
-			store_lanes(rec.vp + outBase + w0, n, make_vu(accVpLo, accVpHi));
-			store_lanes(rec.vn + outBase + w0, n, make_vu(accVnLo, accVnHi));
+			store_lanes(rec.vp + outBase + w0, n, vpV);
+			store_lanes(rec.vn + outBase + w0, n, vnV);
 			store_lanes(rec.before + outBase + w0, n, beforeV);
 			store_lanes(slot.end_cur + outBase + w0, n, packedV);
+			lastEnd = read_lane(endV, n - 1);
 			// minimum end score of the chunk and the LAST column attaining it (:1551-1559, 2410-2418)
 			const VI endLive = select(live, endV, VI(INF));
 			const int chunkMin = read_lane(prefix_min(endLive), LANES - 1);
@@ -585,13 +628,13 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			carryZero = read_lane(zeroV, n - 1);
 			carryBefore = read_lane(beforeV, n - 1);
 			carryAbove2 = read_lane(above2own, n - 1);
-			carryExists = ((existsMask >> (n - 1)) & 1) != 0;
+			carryExists = read_lane(existsV, n - 1) != 0;
 			lastBefore = carryBefore; lastZero = carryZero; lastExists = carryExists;
 		}
 		if (lastBefore != lastZero) return GA_ASSERTION;                         // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
 		if (GA_LANE0)
 		{
-			const int end = lastEndT + 63;
+			const int end = lastEnd;
 			ws.cn_lastVP[s] = vp; ws.cn_lastVN[s] = vn; ws.cn_lastBefore[s] = lastBefore; ws.cn_lastExists[s] = lastExists ? 1 : 0;
 			ws.cn_min[s] = nodeMin; ws.cn_lastEnd[s] = end; ws.cn_lastEnd2[s] = end - (int)(vp >> 63) + (int)(vn >> 63);
 		}
@@ -644,6 +687,8 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		for (uint32_t c = 0; c < seedLen; c += LANES) store_lanes(slot.end_prev + c, (int)(seedLen - c), VI(0));
 	}
 	wave_sync();
+	VI rowNext = load_lanes(rows, W, 0);
+	int rowAboveCode = 0;
 	int prevMin = 0;
 	double logCorrect = hmm.init_correct, logWrong = hmm.init_wrong;
 	uint64_t arenaTop = 0;
@@ -662,9 +707,12 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		GA_LAP(1);
 		if (status != GA_OK) break;
 		if (totalCols > L.cap_cols) { status = GA_CAP_COLS; break; }
-		wave_sync();
+		wave_order();
 		load_topology(g, ws, cn);
-		wave_sync();
+		wave_order();
+		// this slice's row codes arrived during the previous slice; request the next slice's now
+		const VI rowCode = rowNext;
+		if (slice + 1 < numSlices) rowNext = load_lanes(rows + (slice + 1) * W, W, 0);
 		GA_LAP(2);
 		status = processing_order(g, ws, cn);
 		GA_LAP(3);
@@ -677,11 +725,12 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			store_lanes(rec.nodes + c, cn - c, load_lanes(ws.cn_node + c, cn - c, 0));
 			store_lanes(rec.colBase + c, cn - c, load_lanes(ws.cn_colBase + c, cn - c, 0));
 		}
-		wave_sync();
+		wave_order();
 		int sliceMin, minSlot;
 		uint32_t minOffset;
 		GA_LAP(0);
-		status = fill_slice(g, ws, slot, rec, rows, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
+		status = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
+		rowAboveCode = read_lane(rowCode, W - 1);
 		GA_LAP(4);
 		if (status != GA_OK) break;
 		if (sliceMin < prevMin) { status = GA_ASSERTION; break; }                 // :2469
@@ -708,7 +757,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		nPushed++;
 		arenaTop += need;
 		// ---- current band becomes the previous one ----
-		wave_sync();
+		wave_order();
 		for (int c = 0; c < cn; c += LANES)
 		{
 			int k = cn - c;

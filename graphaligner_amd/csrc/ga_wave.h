@@ -55,6 +55,10 @@ inline VU operator&(const VU& a, const VU& b) { VU r; for (int i = 0; i < LANES;
 // lane i receives lane i+1; lane 63 receives `fill`
 inline VI shl1(const VI& x, int fill) { VI r; r.v[LANES - 1] = fill; for (int i = 0; i + 1 < LANES; i++) r.v[i] = x.v[i + 1]; return r; }
 // lane i receives x[idx_i] (idx taken modulo 64)
+// every lane receives x[lane]; the device form goes through the LDS crossbar (ds_bpermute), not the VALU
+inline VI lane_broadcast(const VI& x, int lane) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = x.v[lane & 63]; return r; }
+inline VI shr1v(const VI& x, const VI& fill) { VI r; r.v[0] = fill.v[0]; for (int i = 1; i < LANES; i++) r.v[i] = x.v[i - 1]; return r; }
+inline VI bit_extract_v(const VI& x, const VI& bit) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (x.v[i] >> bit.v[i]) & 1; return r; }
 inline VI lane_gather(const VI& x, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = x.v[idx.v[i] & 63]; return r; }
 // per-lane word with the low `nbits` bits set (nbits <= 0 -> 0, >= 64 -> all)
 inline VU mask_low_bits(const VI& nbits) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = nbits.v[i] <= 0 ? 0ull : nbits.v[i] >= 64 ? ~0ull : ((1ull << nbits.v[i]) - 1); return r; }
@@ -73,6 +77,15 @@ inline VU low_mask_through_lane() { VU r; for (int i = 0; i < LANES; i++) r.v[i]
 inline VI shr1(const VI& x, int fill) { VI r; r.v[0] = fill; for (int i = 1; i < LANES; i++) r.v[i] = x.v[i - 1]; return r; }
 // inclusive prefix minimum over lanes 0..i
 inline VI prefix_min(const VI& x) { VI r; int m = INF; for (int i = 0; i < LANES; i++) { m = x.v[i] < m ? x.v[i] : m; r.v[i] = m; } return r; }
+// the first two / the remaining four steps of the same scan: window minimum over lanes i-3..i, then the rest
+inline VI prefix_min_head(const VI& x) { VI r; for (int i = 0; i < LANES; i++) { int m = x.v[i]; for (int k = 1; k <= 3 && i - k >= (i & ~15); k++) m = x.v[i - k] < m ? x.v[i - k] : m; r.v[i] = m; } return r; }
+inline VI prefix_min_tail(const VI& x)
+{
+	// x is already a width-4 window minimum inside each row of 16 lanes; finish to a full inclusive prefix minimum
+	VI r; int m = INF;
+	for (int i = 0; i < LANES; i++) { m = x.v[i] < m ? x.v[i] : m; r.v[i] = m; }
+	return r;
+}
 inline uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < LANES; i++) if (c.v[i]) m |= 1ull << i; return m; }
 inline int read_lane(const VI& x, int lane) { return x.v[lane]; }
 inline VI write_lane(VI x, int value, int lane) { x.v[lane] = value; return x; }
@@ -88,6 +101,7 @@ inline VU load_lanes_u64(const uint64_t* p, int count) { VU r; for (int i = 0; i
 template <typename T> inline VI gather(const T* p, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)p[idx.v[i]]; return r; }
 template <typename T> inline void scatter(T* p, const VI& idx, const VI& x, const VB& m) { for (int i = 0; i < LANES; i++) if (m.v[i]) p[idx.v[i]] = (T)x.v[i]; }
 inline void wave_sync() {}
+inline void wave_order() {}
 inline uint64_t stamp() { return 0; }
 // one reservation for the whole wave; every lane sees the old value
 inline uint64_t wave_atomic_add(uint64_t* p, uint64_t v) { uint64_t r = *p; *p += v; return r; }
@@ -107,6 +121,11 @@ typedef uint64_t VU;
 // v_mov_b32 dpp wave_shl:1 -- lane 63 has no source lane and keeps `fill`
 GA_FN VI shl1(VI x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
 GA_FN VI lane_gather(VI x, VI idx) { return __builtin_amdgcn_ds_bpermute((idx & 63) << 2, x); }
+// v_readlane costs ~5 SIMD cycles on gfx950 (tools/ubench_valu.hip); a uniform-address ds_bpermute gives the
+// same value in a VGPR on the LDS pipe instead
+GA_FN VI lane_broadcast(VI x, int lane) { return __builtin_amdgcn_ds_bpermute((lane & 63) << 2, x); }
+GA_FN VI shr1v(VI x, VI fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+GA_FN VI bit_extract_v(VI x, VI bit) { return (int)__builtin_amdgcn_ubfe((unsigned)x, (unsigned)bit, 1u); }
 GA_FN VU mask_low_bits(VI nbits) { return nbits <= 0 ? 0ull : nbits >= 64 ? ~0ull : ((1ull << nbits) - 1); }
 GA_FN VI lane_iota() { return (int)threadIdx.x; }
 GA_FN VI vmin(VI a, VI b) { return a < b ? a : b; }
@@ -126,6 +145,24 @@ GA_FN VI prefix_min(VI v)
 	const int ID = 0x7fffffff;
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x143, 0xc, 0xf, false));
+	return v;
+}
+// the scan split in two: most columns are settled by the first two steps (no vertical run longer
+// than three rows ends in them), which the caller detects from the deltas it computes anyway
+GA_FN VI prefix_min_head(VI v)
+{
+	const int ID = 0x7fffffff;
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));
+	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));
+	return v;
+}
+GA_FN VI prefix_min_tail(VI v)
+{
+	const int ID = 0x7fffffff;
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));
@@ -153,6 +190,8 @@ template <typename T> GA_FN VI gather(const T* p, VI idx) { return (int)p[idx]; 
 template <typename T> GA_FN void scatter(T* p, VI idx, VI x, VB m) { if (m) p[idx] = (T)x; }
 // one wave per workgroup: orders this wave's LDS / global traffic (s_waitcnt + s_barrier)
 GA_FN void wave_sync() { __syncthreads(); }
+// compiler-only ordering point: a single wave executes its LDS traffic in order, no wait is needed
+GA_FN void wave_order() { __builtin_amdgcn_wave_barrier(); }
 #ifdef GA_STAMPS
 GA_FN uint64_t stamp() { return __builtin_readcyclecounter(); }
 #else
