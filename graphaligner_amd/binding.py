@@ -182,10 +182,19 @@ class Batch:
         d["stamps"] = list(st.stamps)
         return d
 
-    def collect(self):
+    def collect(self, summary=False):
+        """summary=True: per-read numpy record array only (status, failed, score, n_mappings, ...), no Python lists"""
         out = C.POINTER(GaResults)()
         _check(self.L, self.L.ga_batch_collect(self.h, C.byref(out)), "ga_batch_collect")
         try:
+            if summary:
+                R = out.contents
+                dt = np.dtype([("status", "<i4"), ("failed", "<i4"), ("score", "<i4"), ("reserved", "<i4"), ("alignment_start", "<u8"),
+                               ("alignment_end", "<u8"), ("query_position", "<u8"), ("first_mapping", "<u8"), ("n_mappings", "<u8"),
+                               ("first_trace", "<u8"), ("n_trace", "<u8"), ("column_updates", "<u8")])
+                assert dt.itemsize == C.sizeof(GaReadResult)
+                buf = C.string_at(R.reads, R.n_reads * dt.itemsize) if R.n_reads else b""
+                return np.frombuffer(buf, dtype=dt).copy()
             return _unpack(out.contents)
         finally:
             self.L.ga_results_free(out)

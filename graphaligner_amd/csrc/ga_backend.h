@@ -39,7 +39,7 @@ class GaBackendBatch
 public:
 	virtual ~GaBackendBatch() {}
 	virtual int run() = 0;                                                   // device work only; returns ga_status
-	virtual int fetch(std::vector<GaJobOut>& outs, std::vector<GaTraceStep>& traces, std::vector<uint64_t>& traceOff) = 0;
+	virtual int fetch(std::vector<GaJobOut>& outs, std::vector<uint8_t>& traceBytes) = 0;     // moves of job i: traceBytes[outs[i].trace_off ..+trace_len)
 	virtual GaRunStats stats() const = 0;
 };
 

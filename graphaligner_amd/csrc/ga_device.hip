@@ -32,7 +32,7 @@ __host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxS
 	l.endCur = at; at = up(at + 4ull * capCols);
 	l.sliceOff = at; at = up(at + 4ull * (maxSlices + 1));
 	l.arena = at; at = up(at + 4ull * arenaWords);
-	l.trace = at; at = up(at + 12ull * traceCap);
+	l.trace = at; at = up(at + 1ull * traceCap + 64);
 	l.flags = at; at = up(at + maxSlices + 1);
 	l.bytes = at;
 	return l;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GA_WAVE
 	slot.end_cur = (uint32_t*)(base + lay.endCur);
 	slot.slice_off = (uint32_t*)(base + lay.sliceOff);
 	slot.arena = (uint32_t*)(base + lay.arena);
-	slot.trace = (GaTraceStep*)(base + lay.trace);
+	slot.trace = base + lay.trace;
 	slot.slice_flags = base + lay.flags;
 	while (true)
 	{
@@ -146,7 +146,7 @@ struct DevBatch : GaBackendBatch
 		if (alloc(&L.trace_top, 2)) return GA_E_DEVICE;
 		uint64_t totalRows = 0;
 		for (auto& j : jobs) totalRows += j.n_rows;
-		L.trace_pool_cap = totalRows + totalRows / 2 + 1024ull * jobs.size() + 4096;
+		L.trace_pool_cap = ((totalRows + totalRows / 2 + 256ull * jobs.size() + 4096) + 3) & ~3ull;
 		if (alloc(&L.traces, L.trace_pool_cap)) return GA_E_DEVICE;
 		// slot geometry: bands of ~300-700 columns are the rule (b = 35 on variation graphs);
 		// anything wider fails with a capacity status and is rerun by the wide variant
@@ -249,7 +249,7 @@ struct DevBatch : GaBackendBatch
 		return 0;
 	}
 
-	int fetch(std::vector<GaJobOut>& o, std::vector<GaTraceStep>& traces, std::vector<uint64_t>& off) override
+	int fetch(std::vector<GaJobOut>& o, std::vector<uint8_t>& traces) override
 	{
 		HIP_OK(hipSetDevice(g->device));
 		o = outs;
@@ -257,9 +257,7 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipMemcpy(&top, L.trace_top, 8, hipMemcpyDeviceToHost));
 		top = std::min<uint64_t>(top, L.trace_pool_cap);
 		traces.resize(top);
-		if (top) HIP_OK(hipMemcpy(traces.data(), L.traces, top * sizeof(GaTraceStep), hipMemcpyDeviceToHost));
-		off.resize(outs.size());
-		for (size_t i = 0; i < outs.size(); i++) off[i] = outs[i].trace_off;
+		if (top) HIP_OK(hipMemcpy(traces.data(), L.traces, top, hipMemcpyDeviceToHost));
 		return 0;
 	}
 	GaRunStats stats() const override { return st; }

@@ -5,10 +5,12 @@
 // happens here; the extension program runs behind ga_backend.h on the GPU.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -597,36 +599,50 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	if (!b || !out || !b->dev || !b->ran) return GA_E_INVALID;
 	const ga_graph& g = *b->g;
 	std::vector<GaJobOut> outs;
-	std::vector<GaTraceStep> steps;
-	std::vector<uint64_t> stepOff;
-	int s = b->dev->fetch(outs, steps, stepOff);
+	std::vector<uint8_t> moves;
+	int s = b->dev->fetch(outs, moves);
 	if (s) return s;
 	b->columnUpdates = 0;
 	b->slicesRun = 0;
 	for (const GaJobOut& o : outs) { b->columnUpdates += o.n_columns; b->slicesRun += o.n_run; }
 	ResultsOwner* R = new ResultsOwner();
-	R->reads.resize(b->reads.size());
 	const int32_t kMax = std::numeric_limits<int32_t>::max();
 
-	// device order is backwards (last row first) and ends with the row "-1" entry
-	// (getTraceFromTable :949-952 pops it and reverses)
+	// The device hands back, per job, the cell the traceback starts in and one byte per backward move
+	// (GA_MOVE_*; a move out of a node's first column names the in-neighbour it enters).  Replaying
+	// them gives the reference's trace, which runs from row 0 upwards (getTraceFromTable :949-952).
 	auto deviceTrace = [&](int64_t job) {
 		Trace t;
 		const GaJobOut& o = outs[job];
-		if (o.n_valid == 0 || o.trace_len < 2) return t;
-		const GaTraceStep* p = steps.data() + stepOff[job];
-		t.resize(o.trace_len - 1);
-		for (uint32_t i = 0; i + 1 < o.trace_len; i++)
+		if (o.n_valid == 0) return t;
+		const uint8_t* mv = moves.data() + o.trace_off;
+		t.resize((size_t)o.trace_len + 1);
+		Pos p{o.start_node, o.start_offset, o.start_row};
+		size_t at = t.size() - 1;
+		t[at] = p;
+		for (uint32_t i = 0; i < o.trace_len; i++)
 		{
-			const GaTraceStep& st = p[o.trace_len - 2 - i];
-			t[i] = Pos{st.node, st.offset, st.row};
+			const int code = mv[i] & 3, via = mv[i] >> 2;
+			if (code != GA_MOVE_LEFT) p.row -= 1;
+			if (code != GA_MOVE_UP)
+			{
+				if (p.offset > 0) p.offset -= 1;
+				else
+				{
+					p.node = g.in[p.node][via];
+					p.offset = g.nodeLen(p.node) - 1;
+				}
+			}
+			t[--at] = p;
 		}
 		return t;
 	};
 
-	for (size_t ri = 0; ri < b->reads.size(); ri++)
+	auto work = [&](size_t lo, size_t hi, ResultsOwner* R) {
+	for (size_t ri = lo; ri < hi; ri++)
 	{
-		ga_read_result_t& rr = R->reads[ri];
+		R->reads.emplace_back();
+		ga_read_result_t& rr = R->reads.back();
 		memset(&rr, 0, sizeof(rr));
 		rr.failed = 1;
 		rr.score = kMax;
@@ -731,6 +747,36 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		rr.query_position = lastAligned;
 		rr.alignment_start = lastAligned;
 		rr.alignment_end = lastAligned + bestEstimate;
+	}
+	};
+	// reads are independent: assemble them on several host threads, then stitch the per-thread arrays
+	size_t nThreads = std::thread::hardware_concurrency();
+	if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
+	nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), b->reads.size() / 64 + 1));
+	std::vector<ResultsOwner> parts(nThreads);
+	{
+		std::vector<std::thread> pool;
+		size_t per = (b->reads.size() + nThreads - 1) / nThreads;
+		for (size_t t = 0; t < nThreads; t++)
+		{
+			size_t lo = std::min(b->reads.size(), t * per), hi = std::min(b->reads.size(), lo + per);
+			pool.emplace_back(work, lo, hi, &parts[t]);
+		}
+		for (auto& th : pool) th.join();
+	}
+	R->reads.clear();
+	for (ResultsOwner& part : parts)
+	{
+		const uint64_t mapBase = R->mappings.size(), editBase = R->edits.size(), traceBase = R->trace.size();
+		for (ga_read_result_t rr : part.reads)
+		{
+			rr.first_mapping += mapBase;
+			rr.first_trace += traceBase;
+			R->reads.push_back(rr);
+		}
+		for (ga_mapping_t m : part.mappings) { m.edit_seq_off += editBase; R->mappings.push_back(m); }
+		R->edits.insert(R->edits.end(), part.edits.begin(), part.edits.end());
+		R->trace.insert(R->trace.end(), part.trace.begin(), part.trace.end());
 	}
 	R->pub.n_reads = R->reads.size(); R->pub.reads = R->reads.data();
 	R->pub.n_mappings = R->mappings.size(); R->pub.mappings = R->mappings.data();

@@ -85,7 +85,7 @@ struct Slot
 	uint32_t* arena;         // slice records
 	uint32_t* slice_off;     // [max_slices] word offset of each slice record
 	uint8_t* slice_flags;    // [max_slices] bit0 currentlyCorrect, bit1 falseFromCorrect
-	GaTraceStep* trace;      // [trace_cap] staging for the traceback of the current job
+	uint8_t* trace;          // [trace_cap] staging for the traceback moves of the current job
 };
 
 GA_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
@@ -666,6 +666,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	Slot slot = slotIn;
 	GaJobOut out;
 	out.status = GA_OK; out.score = 0x7fffffff; out.n_valid = 0; out.n_run = 0; out.trace_len = 0; out.max_band_nodes = 0; out.n_columns = 0; out.trace_off = 0;
+	out.start_node = 0; out.start_offset = 0; out.start_row = 0; out.reserved2 = 0;
 	for (int i = 0; i < 8; i++) out.stamps[i] = 0;
 	uint64_t tA = stamp(), tB;
 #define GA_LAP(i) do { tB = stamp(); out.stamps[i] += tB - tA; tA = tB; } while (0)
@@ -800,7 +801,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	}
 	if (status == GA_OK && kept > 0)
 	{
-		GaTraceStep* tr = slot.trace;
+		uint8_t* tr = slot.trace;
 		const int big = (int)job.n_rows;                                         // getValueOrMax default = sequence.size()
 		uint32_t sIdx = kept - 1;
 		uint32_t off = slot.slice_off[sIdx];
@@ -811,6 +812,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		uint32_t offset = cur.hdr[4];
 		uint32_t row = sIdx * W + (W - 1);
 		uint32_t len = 0;
+		out.start_node = node; out.start_offset = offset; out.start_row = row;
 		SliceRec prv = cur;
 		uint32_t pN = 0;
 		auto loadPrev = [&]() {
@@ -854,10 +856,8 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		};
 		while (true)
 		{
-			if (len >= L.trace_cap) { status = GA_CAP_TRACE; break; }
-			if (GA_LANE0) { tr[len].node = node; tr[len].offset = offset; tr[len].row = row; }
-			len++;
 			if (row == 0xffffffffu) break;                                       // reached the row before the first one
+			if (len + LANES >= L.trace_cap) { status = GA_CAP_TRACE; break; }
 			const int r = (int)(row - sIdx * W);
 			if (rowvSlice != sIdx) { rowv = load_lanes(rows + sIdx * W, W, 0); rowvSlice = sIdx; }
 			// ---- make the current window cover this column (and its left neighbour when there is one) ----
@@ -901,15 +901,9 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				run = run < rel ? run : rel;
 				if (run >= 2)
 				{
-					// positions 1 .. run-1 of the run go out in one scatter; position `run` is recorded by the next iteration
-					if (len + (uint32_t)run > L.trace_cap) { status = GA_CAP_TRACE; break; }
-					const VB mine = (lane < rel) && (lane > rel - run);
-					const VI at3 = (VI((int)len) + (rel - 1) - lane) * 3;
-					uint32_t* trw = (uint32_t*)tr;
-					scatter(trw, at3, VI((int)node), mine);
-					scatter(trw, at3 + 1, lane + cw.lo, mine);
-					scatter(trw, at3 + 2, rho + (int)(sIdx * W), mine);
-					len += (uint32_t)(run - 1);
+					// the whole run is `run` diagonal moves inside the node
+					store_lanes(tr + len, run, VI(GA_MOVE_DIAG));
+					len += (uint32_t)run;
 					offset -= (uint32_t)run;
 					row -= (uint32_t)run;
 					continue;
@@ -939,6 +933,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			}
 			(void)upKnown;
 			int res = 0;
+			int viaNeighbour = 0;                                                // ordinal of the in-neighbour a move enters (0 inside a node)
 			const uint32_t curNode = node, curOffset = offset;
 			auto decide = [&](int horizontal, int diagonal, uint32_t un, uint32_t uo) -> int {
 				if (horizontal < here - 1) return -1;
@@ -961,6 +956,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				{
 					uint32_t m = g.in_nbr[e];
 					uint32_t mo = g_len(g, m) - 1;
+					viaNeighbour = (int)(e - g.in_off[curNode]);
 					int horizontal = stored_value(cur, nN, m, mo, r, big);
 					int diagonal = 0;
 					if (horizontal > here - 1) diagonal = r == 0 ? valuePrevLastRow(m, mo) : stored_value(cur, nN, m, mo, r - 1, big);
@@ -974,9 +970,17 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				int up = read_lane(valUp, rel);
 				if (up != here - 1) { status = GA_ASSERTION; break; }            // assert(false) (:588)
 				row = row - 1;
-				res = 2;
+				res = 3;
 			}
-			if (res == 2 && r == 0 && row != 0xffffffffu)
+			// put the move away (the step onto the row before the first one is not part of the trace, :949-950)
+			if (row != 0xffffffffu)
+			{
+				if (viaNeighbour > 62) { status = GA_CAP_TRACE; break; }
+				const int code = res == 1 ? GA_MOVE_LEFT : res == 2 ? GA_MOVE_DIAG : GA_MOVE_UP;
+				if (GA_LANE0) tr[len] = (uint8_t)(code | (res == 3 ? 0 : (viaNeighbour << 2)));
+				len++;
+			}
+			if (res >= 2 && r == 0 && row != 0xffffffffu)
 			{
 				// stepped into the slice above
 				sIdx--;
@@ -989,13 +993,14 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		if (status == GA_OK)
 		{
 			wave_sync();
-			uint64_t at = wave_atomic_add(L.trace_top, (uint64_t)len);
-			if (at + len > L.trace_pool_cap) status = GA_CAP_TRACE;
+			const uint32_t words = (len + 3) / 4;
+			uint64_t at = wave_atomic_add(L.trace_top, (uint64_t)words * 4);
+			if (at + (uint64_t)words * 4 > L.trace_pool_cap) status = GA_CAP_TRACE;
 			else
 			{
 				uint32_t* dst = (uint32_t*)(L.traces + at);
 				const uint32_t* src = (const uint32_t*)tr;
-				for (uint32_t c = 0; c < 3 * len; c += LANES) store_lanes(dst + c, (int)(3 * len - c), load_lanes(src + c, (int)(3 * len - c), 0));
+				for (uint32_t c = 0; c < words; c += LANES) store_lanes(dst + c, (int)(words - c), load_lanes(src + c, (int)(words - c), 0));
 				out.trace_off = at;
 				out.trace_len = len;
 			}

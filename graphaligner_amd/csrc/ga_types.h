@@ -49,14 +49,17 @@ struct GaJobOut {
 	int32_t score;         // min score of the last kept slice (INT32_MAX when nothing was kept)
 	uint32_t n_valid;      // slices kept after trimming (= bandwidthPerSlice.size())
 	uint32_t n_run;        // slices computed in the first pass
-	uint32_t trace_len;    // trace steps written (backwards: last row first)
+	uint32_t trace_len;    // backward moves written (one byte each), from the start cell down to row 0
 	uint32_t max_band_nodes;
 	uint64_t n_columns;    // column updates = sum over computed slices of band columns
-	uint64_t trace_off;    // first step of this job inside the trace pool
+	uint64_t trace_off;    // byte offset of this job's moves inside the trace pool
+	uint32_t start_node, start_offset, start_row, reserved2;   // where the traceback starts (last kept slice, last row)
 	uint64_t stamps[8];    // diagnostic builds only (GA_STAMPS): shader cycles per phase; zero otherwise
 };
 
-struct GaTraceStep { uint32_t node, offset, row; };
+// one traceback move, one byte: bits 0-1 = 0 left (same row), 1 diagonal, 2 up (same column);
+// bits 2-7 = which in-neighbour (insertion order) the move enters when it leaves a node's first column
+enum { GA_MOVE_LEFT = 0, GA_MOVE_DIAG = 1, GA_MOVE_UP = 2 };
 
 struct GaLaunch {
 	GaDevGraph graph;
@@ -64,15 +67,15 @@ struct GaLaunch {
 	const uint8_t* rows;        // row codes: bits 0-3 match mask over A,C,G,T; bits 4-6 exact code (7 = none); bit 7 invalid char
 	const GaJob* jobs;
 	GaJobOut* outs;
-	GaTraceStep* traces;        // trace pool; each finished job claims exactly trace_len entries
-	uint64_t* trace_top;        // device bump counter over the pool
-	uint64_t trace_pool_cap;    // entries
+	uint8_t* traces;            // trace pool (bytes); each finished job claims its moves, rounded up to 4 bytes
+	uint64_t* trace_top;        // device bump counter over the pool (bytes)
+	uint64_t trace_pool_cap;    // bytes
 	const uint32_t* job_list;   // optional indirection (retry launches): job index = job_list[k]; nullptr = identity
 	uint32_t* next_job;         // device work counter
 	uint8_t* scratch;           // [n_slots][slot_bytes]
 	uint64_t slot_bytes;
 	uint32_t n_jobs;
-	uint32_t trace_cap;         // per-slot staging capacity (steps)
+	uint32_t trace_cap;         // per-slot staging capacity (moves = bytes)
 	uint32_t cap_cols;          // end-score buffer capacity per slice (columns)
 	uint32_t max_slices;        // per job
 	uint64_t arena_words;       // u32 words of slice storage per slot

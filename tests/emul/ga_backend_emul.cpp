@@ -31,7 +31,7 @@ struct EmulBatch : GaBackendBatch
 	std::vector<GaJob> jobs;
 	GaRunConfig cfg;
 	std::vector<GaJobOut> outs;
-	std::vector<GaTraceStep> pool;
+	std::vector<uint8_t> pool;
 	uint64_t poolTop = 0;
 	uint64_t retried = 0;
 
@@ -39,7 +39,7 @@ struct EmulBatch : GaBackendBatch
 	{
 		std::vector<uint32_t> endA(capCols), endB(capCols), arena(arenaWords), sliceOff(cfg.max_slices + 1);
 		std::vector<uint8_t> flags(cfg.max_slices + 1);
-		std::vector<GaTraceStep> staging(traceCap);
+		std::vector<uint8_t> staging(traceCap + 64);
 		gak::Slot slot{endA.data(), endB.data(), arena.data(), sliceOff.data(), flags.data(), staging.data()};
 		GaLaunch L;
 		memset(&L, 0, sizeof(L));
@@ -56,7 +56,7 @@ struct EmulBatch : GaBackendBatch
 		outs.assign(jobs.size(), GaJobOut{});
 		uint64_t totalRows = 0;
 		for (auto& j : jobs) totalRows += j.n_rows;
-		pool.assign(totalRows * 3 + 4096 * jobs.size() + 64, GaTraceStep{});
+		pool.assign(totalRows * 3 + 4096 * jobs.size() + 64, 0);
 		poolTop = 0;
 		retried = 0;
 		for (uint32_t j = 0; j < jobs.size(); j++)
@@ -73,12 +73,10 @@ struct EmulBatch : GaBackendBatch
 		}
 		return 0;
 	}
-	int fetch(std::vector<GaJobOut>& o, std::vector<GaTraceStep>& traces, std::vector<uint64_t>& off) override
+	int fetch(std::vector<GaJobOut>& o, std::vector<uint8_t>& traces) override
 	{
 		o = outs;
 		traces.assign(pool.begin(), pool.begin() + poolTop);
-		off.resize(outs.size());
-		for (size_t i = 0; i < outs.size(); i++) off[i] = outs[i].trace_off;
 		return 0;
 	}
 	GaRunStats stats() const override { GaRunStats s; s.jobs_retried = retried; s.slots = 1; return s; }
