@@ -52,12 +52,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the aligner has no CPU path")
+    # GA_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("GA_BENCH_BACKEND", "nccl")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     import __graft_entry__ as entry
     entry.build_product()
@@ -94,7 +98,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -107,7 +111,7 @@ def main():
     aligned_bp = int(lens[summary["failed"] == 0].sum())
     n_failed = int((summary["failed"] != 0).sum())
     if world > 1:
-        t = torch.tensor([float(aligned_bp)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(aligned_bp)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         aligned_total = float(t.item())
     else:
@@ -122,6 +126,12 @@ def main():
     value = aligned_total / (elapsed / args.steps) / 1e9
     k_ms = float(np.mean(kernel_ms))
     achieved = BYTES_PER_COLUMN_UPDATE * st["column_updates"] / (k_ms * 1e-3) / 1e9
+    # HBM traffic per launch: PMC counters cannot be read from inside this process, so the per-column-update
+    # figure measured with rocprofv3 --pmc on this kernel (profiles/r1_hbm_traffic.json) is scaled to this launch
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+    if os.path.exists(tpath):
+        traffic = int(json.load(open(tpath))["hbm_bytes_per_column_update"] * st["column_updates"])
     out = {
         "metric": "aligned Gbp/sec (whole node), 10kb ONT reads vs chr-scale GFA",
         "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -133,7 +143,7 @@ def main():
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "bandwidth": args.bandwidth, "graph_bp_both_strands": int(graph.bp),
                    "parallelism": "reads sharded, graph replicated, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": None, "kernel": "ga_extend_kernel<32>", "kernel_ms": round(k_ms, 3),
+                     "traffic": traffic, "kernel": "ga_extend_kernel<32>", "kernel_ms": round(k_ms, 3),
                      "column_updates_per_launch": int(st["column_updates"]), "bytes_per_column_update": BYTES_PER_COLUMN_UPDATE},
         "detail": {"reads_failed": n_failed, "jobs": int(st["n_jobs"]), "jobs_retried_wide": int(st["jobs_retried"]), "slots": int(st["slots"]),
                    "scratch_GB": round(st["scratch_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "prepare_s": round(t_prep, 1), "collect_s": round(t_collect, 2), "end_to_end_Gbp_s_incl_collect": round(aligned_bp / (k_ms * 1e-3 + t_collect) / 1e9, 3),
