@@ -51,3 +51,14 @@ def test_full_size_properties():
 def test_golden_vectors():
     import test_oracle_golden as tg
     tg.run_device_on_golden(None)
+
+
+def test_randomised_campaign():
+    """a few hundred reads over random graph shapes, bandwidths, error rates, seed positions"""
+    import subprocess, sys, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "parity_campaign.py"), "--trials", "30", "--reads", "16", "--seed", "5"],
+                         capture_output=True, text=True, timeout=600)
+    stats = json.loads(out.stdout.strip().split("\n")[-1])
+    assert stats["mismatches"] == 0, stats
+    assert stats["compared"] >= 300

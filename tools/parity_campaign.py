@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign: many small graphs x reads through the C ABI (GPU library by default,
+--emul for the host emulation of the device program) and through the CPU oracle; every field of
+every result is compared (tests/parity_common.compare_read).  Prints a JSON summary."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=60)
+    ap.add_argument("--reads", type=int, default=24)
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--emul", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    from graphaligner_amd import synth
+    import parity_common as pc
+    lib = pc.emul_lib_path() if args.emul else None
+    rng = np.random.default_rng(args.seed)
+    stats = dict(reads=0, compared=0, mismatches=0, dev_status={}, first_mismatches=[])
+    t0 = time.time()
+    for trial in range(args.trials):
+        nl = int(rng.choice([3, 8, 16, 32, 64, 100]))
+        snp = int(rng.choice([0, 25, 60, 100]))
+        indel = int(rng.choice([0, 100, 400, 1000]))
+        sv = int(rng.choice([0, 0, 2500]))
+        g = synth.SynthGraph(synth.random_genome(int(rng.choice([6000, 15000, 40000])), 7000 + trial), node_len=nl, snp_every=snp, indel_every=indel, sv_every=sv, seed=trial)
+        L = int(rng.choice([300, 700, 1500, 3000, 6000]))
+        bw = int(rng.choice([2, 8, 20, 35, 35, 35, 50, 90]))
+        err = float(rng.choice([0.0, 0.01, 0.04, 0.04, 0.08]))
+        mid = bool(rng.random() < 0.4)
+        try:
+            reads, seeds = synth.simulate_reads(g, args.reads, L, sub=err, ins=err, dele=err, seed=trial, mid_seed=mid)
+        except RuntimeError:
+            continue
+        # sprinkle IUPAC / N / lower case into some reads
+        for k in range(0, len(reads), 5):
+            b = bytearray(reads[k].encode())
+            for _ in range(8):
+                b[int(rng.integers(len(b)))] = ord("NRYKMSWBDVnacgt"[int(rng.integers(15))])
+            reads[k] = b.decode()
+        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, lib_path=lib)
+        for i, (d, o) in enumerate(zip(devs, oras)):
+            stats["reads"] += 1
+            stats["dev_status"][str(d["status"])] = stats["dev_status"].get(str(d["status"]), 0) + 1
+            if d["status"] in (10, 20, 21):
+                continue      # reported as unsupported / capacity: never a silently different answer
+            stats["compared"] += 1
+            try:
+                pc.compare_read(d, o, "trial %d read %d" % (trial, i))
+            except AssertionError as e:
+                stats["mismatches"] += 1
+                if len(stats["first_mismatches"]) < 5:
+                    stats["first_mismatches"].append(dict(trial=trial, node_len=nl, snp=snp, indel=indel, sv=sv, L=L, bw=bw, err=err, mid=mid, what=str(e)[:300]))
+    stats["seconds"] = round(time.time() - t0, 1)
+    print(json.dumps(stats))
+    return 1 if stats["mismatches"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
