@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--genome", type=int, default=4641652)
     ap.add_argument("--node-len", type=int, default=64)
     ap.add_argument("--bandwidth", type=int, default=35)
-    ap.add_argument("--graph", choices=["linear", "bubbles"], default="linear")
+    ap.add_argument("--graph", choices=["linear", "bubbles", "dense"], default="linear")
+    ap.add_argument("--errors", default="0.04,0.04,0.04", help="substitution,insertion,deletion rates of the read simulator")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build with per-phase cycle stamps (not a timed build)")
     ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
@@ -70,9 +71,13 @@ def main():
     t0 = time.time()
     if args.graph == "linear":
         g = synth.linear_graph(args.genome, node_len=args.node_len, seed=42)
-    else:
+    elif args.graph == "bubbles":
         g = synth.bubble_graph(args.genome, node_len=args.node_len, seed=44)
-    reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=0.04, ins=0.04, dele=0.04, seed=43 + 1000 * rank)
+    else:
+        # chr22-like density: ~1 SNP per 45 bp, short indels, 32-bp nodes
+        g = synth.SynthGraph(synth.random_genome(args.genome, 47), node_len=args.node_len, snp_every=45, indel_every=500, seed=48)
+    e_sub, e_ins, e_del = (float(x) for x in args.errors.split(","))
+    reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=e_sub, ins=e_ins, dele=e_del, seed=43 + 1000 * rank)
     t_gen = time.time() - t0
     t0 = time.time()
     lib_path = entry.build_stamped() if args.stamps else args.lib

@@ -53,10 +53,14 @@ class GaBatchStats(C.Structure):
                 ("scratch_bytes", C.c_uint64), ("stamps", C.c_uint64 * 8)]
 
 
+class GaNamedSeed(C.Structure):
+    _fields_ = [("read_name", C.c_char_p), ("seed", GaSeed)]
+
+
 EXPORTS = ["ga_graph_create", "ga_graph_destroy", "ga_graph_add_node", "ga_graph_add_edge", "ga_graph_add_bigraph_node",
            "ga_graph_add_bigraph_edge", "ga_graph_finalize", "ga_graph_load_gfa", "ga_graph_upload", "ga_graph_node_count", "ga_graph_bp",
            "ga_align_batch", "ga_results_free", "ga_batch_prepare", "ga_batch_run", "ga_batch_collect", "ga_batch_free", "ga_batch_stats",
-           "ga_status_string", "ga_version"]
+           "ga_graph_load_vg", "ga_gam_decode_seeds", "ga_results_encode_gam", "ga_bytes_free", "ga_status_string", "ga_version"]
 
 _libs = {}
 
@@ -89,6 +93,10 @@ def load(path=None):
     L.ga_batch_collect.argtypes = [C.c_void_p, C.c_void_p]
     L.ga_batch_free.argtypes = [C.c_void_p]
     L.ga_batch_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.ga_graph_load_vg.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ga_gam_decode_seeds.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ga_results_encode_gam.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ga_bytes_free.argtypes = [C.c_void_p]
     L.ga_status_string.argtypes = [C.c_int]
     L.ga_status_string.restype = C.c_char_p
     L.ga_version.restype = C.c_char_p
@@ -104,10 +112,12 @@ def _check(L, s, what):
 class Graph:
     """AlignmentGraph built the way the reference's loaders build it, then copied to HBM"""
 
-    def __init__(self, nodes=None, edges=None, overlap=0, gfa=None, device=0, lib_path=None):
+    def __init__(self, nodes=None, edges=None, overlap=0, gfa=None, vg=None, device=0, lib_path=None):
         self.L = load(lib_path)
         self.h = self.L.ga_graph_create()
-        if gfa is not None:
+        if vg is not None:
+            _check(self.L, self.L.ga_graph_load_vg(self.h, vg, len(vg)), "ga_graph_load_vg")
+        elif gfa is not None:
             data = gfa.encode() if isinstance(gfa, str) else gfa
             _check(self.L, self.L.ga_graph_load_gfa(self.h, data, len(data)), "ga_graph_load_gfa")
         else:
@@ -182,6 +192,19 @@ class Batch:
         d["stamps"] = list(st.stamps)
         return d
 
+    def collect_gam(self, halve_node_ids=True):
+        """align results as the bytes of a GAM file (what the reference's driver writes, Aligner.cpp:301-314)"""
+        out = C.POINTER(GaResults)()
+        _check(self.L, self.L.ga_batch_collect(self.h, C.byref(out)), "ga_batch_collect")
+        try:
+            buf, n = C.c_void_p(), C.c_size_t()
+            _check(self.L, self.L.ga_results_encode_gam(out, self._arr, int(halve_node_ids), C.byref(buf), C.byref(n)), "ga_results_encode_gam")
+            data = C.string_at(buf, n.value)
+            self.L.ga_bytes_free(buf)
+            return data
+        finally:
+            self.L.ga_results_free(out)
+
     def collect(self, summary=False):
         """summary=True: per-read numpy record array only (status, failed, score, n_mappings, ...), no Python lists"""
         out = C.POINTER(GaResults)()
@@ -205,6 +228,16 @@ class Batch:
                 self.L.ga_batch_free(self.h)
         except Exception:
             pass
+
+
+def decode_seed_gam(data, lib_path=None):
+    """[(read name, (node, pos, reverse)), ...] from the bytes of a seed GAM file (Aligner.cpp:253-271)"""
+    L = load(lib_path)
+    arr, n = C.POINTER(GaNamedSeed)(), C.c_size_t()
+    _check(L, L.ga_gam_decode_seeds(data, len(data), C.byref(arr), C.byref(n)), "ga_gam_decode_seeds")
+    out = [(arr[i].read_name.decode(), (arr[i].seed.node_id, arr[i].seed.read_pos, bool(arr[i].seed.reverse))) for i in range(n.value)]
+    L.ga_bytes_free(arr)
+    return out
 
 
 def _unpack(R):

@@ -195,57 +195,64 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipEventElapsedTime(&ms, evStart, evStop));
 		st.kernel_ms = ms;
 		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
-		// ---- capacity misses go through the wide variant (256 band nodes in LDS, larger buffers) ----
+		// ---- capacity misses climb a ladder of wider variants: 64 band nodes in LDS, then 256 with large buffers ----
+		st.jobs_retried = 0;
+		int rc = retryPass<64>(8192, 2 * 64 + 5 * 2048, 3, 12);
+		if (rc) return rc;
+		rc = retryPass<256>(65536, 2 * 256 + 5 * 8192, 6, 4);
+		return rc;
+	}
+
+	static bool isCapacity(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; }
+
+	template <int MAXN> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry)
+	{
 		std::vector<uint32_t> again;
-		for (uint32_t i = 0; i < outs.size(); i++)
+		for (uint32_t i = 0; i < outs.size(); i++) if (isCapacity(outs[i].status)) again.push_back(i);
+		if (again.empty()) return 0;
+		st.jobs_retried += again.size();
+		GaLaunch R = L;
+		uint32_t maxRows = 0;
+		for (uint32_t i : again) maxRows = std::max(maxRows, jobs[i].n_rows);
+		R.cap_cols = capCols;
+		R.trace_cap = maxRows * traceMul + 4096;
+		R.arena_words = 64 + (uint64_t)(maxRows / 64) * (gak::kSliceHdrWords + arenaWordsPerSlice);
+		SlotLayout lay = slotLayout(R.cap_cols, R.max_slices, R.arena_words, R.trace_cap);
+		R.slot_bytes = lay.bytes;
+		size_t freeB = 0, totalB = 0;
+		HIP_OK(hipMemGetInfo(&freeB, &totalB));
+		uint64_t fit = (uint64_t)((freeB + retryScratchBytes) * 0.8) / lay.bytes;
+		uint32_t rslots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * wavesPerCuRetry, fit), again.size()));
+		if ((size_t)rslots * lay.bytes > retryScratchBytes)
 		{
-			int s = outs[i].status;
-			if (s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP) again.push_back(i);
+			if (retryScratch) hipFree(retryScratch);
+			retryScratch = nullptr;
+			retryScratchBytes = 0;
+			HIP_OK(hipMalloc((void**)&retryScratch, (size_t)rslots * lay.bytes));
+			retryScratchBytes = (size_t)rslots * lay.bytes;
 		}
-		st.jobs_retried = again.size();
-		if (!again.empty())
-		{
-			GaLaunch R = L;
-			uint32_t maxRows = 0;
-			for (uint32_t i : again) maxRows = std::max(maxRows, jobs[i].n_rows);
-			R.cap_cols = 65536;
-			R.trace_cap = maxRows * 6 + 4096;
-			R.arena_words = 64 + (uint64_t)(maxRows / 64) * (gak::kSliceHdrWords + 2 * 256 + 5 * 8192);
-			SlotLayout lay = slotLayout(R.cap_cols, R.max_slices, R.arena_words, R.trace_cap);
-			R.slot_bytes = lay.bytes;
-			size_t freeB = 0, totalB = 0;
-			HIP_OK(hipMemGetInfo(&freeB, &totalB));
-			uint64_t fit = (uint64_t)(freeB * 0.8) / lay.bytes;
-			uint32_t rslots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * 4, fit), again.size()));
-			if ((size_t)rslots * lay.bytes > retryScratchBytes)
-			{
-				if (retryScratch) hipFree(retryScratch);
-				retryScratch = nullptr;
-				HIP_OK(hipMalloc((void**)&retryScratch, (size_t)rslots * lay.bytes));
-				retryScratchBytes = (size_t)rslots * lay.bytes;
-			}
-			if (retryList) hipFree(retryList);
-			HIP_OK(hipMalloc((void**)&retryList, again.size() * 4));
-			HIP_OK(hipMemcpyAsync(retryList, again.data(), again.size() * 4, hipMemcpyHostToDevice, stream));
-			R.scratch = retryScratch;
-			R.job_list = retryList;
-			R.n_jobs = (uint32_t)again.size();
-			HIP_OK(hipMemsetAsync(R.next_job, 0, 16, stream));
-			hipEvent_t a, b;
-			HIP_OK(hipEventCreate(&a));
-			HIP_OK(hipEventCreate(&b));
-			HIP_OK(hipEventRecord(a, stream));
-			hipLaunchKernelGGL(ga_extend_kernel<256>, dim3(rslots), dim3(64), 0, stream, R);
-			HIP_OK(hipGetLastError());
-			HIP_OK(hipEventRecord(b, stream));
-			HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));
-			HIP_OK(hipStreamSynchronize(stream));
-			float ms2 = 0;
-			HIP_OK(hipEventElapsedTime(&ms2, a, b));
-			st.kernel_ms += ms2;
-			hipEventDestroy(a);
-			hipEventDestroy(b);
-		}
+		if (retryList) hipFree(retryList);
+		retryList = nullptr;
+		HIP_OK(hipMalloc((void**)&retryList, again.size() * 4));
+		HIP_OK(hipMemcpyAsync(retryList, again.data(), again.size() * 4, hipMemcpyHostToDevice, stream));
+		R.scratch = retryScratch;
+		R.job_list = retryList;
+		R.n_jobs = (uint32_t)again.size();
+		HIP_OK(hipMemsetAsync(R.next_job, 0, 16, stream));
+		hipEvent_t a, b;
+		HIP_OK(hipEventCreate(&a));
+		HIP_OK(hipEventCreate(&b));
+		HIP_OK(hipEventRecord(a, stream));
+		hipLaunchKernelGGL(ga_extend_kernel<MAXN>, dim3(rslots), dim3(64), 0, stream, R);
+		HIP_OK(hipGetLastError());
+		HIP_OK(hipEventRecord(b, stream));
+		HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipStreamSynchronize(stream));
+		float ms2 = 0;
+		HIP_OK(hipEventElapsedTime(&ms2, a, b));
+		st.kernel_ms += ms2;
+		hipEventDestroy(a);
+		hipEventDestroy(b);
 		return 0;
 	}
 

@@ -26,6 +26,9 @@ using namespace gaw;
 constexpr int W = 64;
 constexpr uint32_t kCutoff = 200000;         // GraphAlignerCommon.h:10
 constexpr int kSliceHdrWords = 6;
+#ifndef GA_TWO_STAGE_SCAN
+#define GA_TWO_STAGE_SCAN 0
+#endif
 #ifndef GA_ABLATE
 #define GA_ABLATE 0          // timing experiments only (results are wrong when non-zero)
 #endif
@@ -599,8 +602,21 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, c - 1);
 				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), c - 1);
 #endif
+#if GA_TWO_STAGE_SCAN
+				// two scan steps settle the column unless a vertical run longer than three rows ends in it; that
+				// shows as a lane whose T exceeds the T of the row above (T must be non-increasing down the column)
+				const VI head = prefix_min_head(G);
+				T = vmin(head, bp1v);
+				sh = shr1v(T, bp1v);
+				if (ballot(T > sh))
+				{
+					T = vmin(prefix_min_tail(head), bp1v);
+					sh = shr1v(T, bp1v);
+				}
+#else
 				T = vmin(prefix_min(G), bp1v);
 				sh = shr1v(T, bp1v);
+#endif
 				Tp1 = T + 1;
 			}
 			vp = ballot(T == sh);

@@ -154,6 +154,18 @@ typedef struct ga_batch_stats {
 } ga_batch_stats_t;
 int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out);
 
+/* ---- file formats either side of the path (no libprotobuf; zlib only) --------------------------------- */
+/* gzip-framed vg.Graph chunks (stream.hpp:24-118) -> graph, as DirectedGraph::StreamVGGraphFromFile
+ * (BigraphToDigraph.cpp:106-135): all nodes first, then all edges, then Finalize; DBGOverlap stays 0 */
+int ga_graph_load_vg(ga_graph_t* g, const void* bytes, size_t len);
+/* seed GAM -> (read name, seed hit): mapping(0).position().node_id / is_reverse, query_position (Aligner.cpp:253-271) */
+typedef struct ga_named_seed { const char* read_name; ga_seed_t seed; } ga_named_seed_t;
+int ga_gam_decode_seeds(const void* bytes, size_t len, ga_named_seed_t** out, size_t* n);   /* free with ga_bytes_free(*out) */
+/* results -> one GAM group of vg.Alignment (Aligner.cpp:301-314); failed reads are skipped (Aligner.cpp:153-164);
+ * halve_node_ids applies replaceDigraphNodeIdsWithOriginalNodeIds (Aligner.cpp:83-91) */
+int ga_results_encode_gam(const ga_results_t* r, const ga_read_t* reads, int halve_node_ids, void** out, size_t* out_len);
+void ga_bytes_free(void* p);
+
 const char* ga_status_string(int status);
 const char* ga_version(void);
 

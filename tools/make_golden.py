@@ -131,6 +131,11 @@ def main():
         json.dump(dict(source="reference test/smallexample/{sub_test.vg,read.fastq,seedalignment.gam} (data files, decoded)", nodes=n, edges=e,
                        read_name=fq[0][1:], read=fq[1], seeds=seeds), open(os.path.join(OUT, "ref_smallexample.json"), "w"))
 
+        import shutil
+        shutil.copy(os.path.join(REF, "test", "gwws_fail_ex1.vg"), os.path.join(OUT, "ref_gwws_fail_ex1.vg"))
+        shutil.copy(os.path.join(REF, "test", "smallexample", "sub_test.vg"), os.path.join(OUT, "ref_smallexample_sub_test.vg"))
+        shutil.copy(os.path.join(REF, "test", "smallexample", "seedalignment.gam"), os.path.join(OUT, "ref_smallexample_seedalignment.gam"))
+
     # ---- 2. oracle-generated golden vectors ----
     cases = []
     specs = [("linear64", dict(node_len=64), 35, False), ("snp32", dict(node_len=32, snp_every=60), 35, True),
