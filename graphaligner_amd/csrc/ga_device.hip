@@ -203,7 +203,8 @@ struct DevBatch : GaBackendBatch
 		return rc;
 	}
 
-	static bool isCapacity(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; }
+	// statuses a wider kernel variant can resolve: capacity misses, and bands with cycles (only the wide variants carry that path)
+	static bool isCapacity(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP || s == GA_UNSUPPORTED_CYCLE; }
 
 	template <int MAXN> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry)
 	{

@@ -71,6 +71,8 @@ template <int MAXN> struct WaveState
 	uint32_t cn_inNbr[MAXN * 4], cn_outNbr[MAXN * 4];
 	uint8_t color[MAXN];
 	int16_t post[MAXN];          // Tarjan emission order
+	int16_t low[MAXN];           // Tarjan low-link / component number (bands with cycles only)
+	int16_t comp[MAXN];
 	// scratch: hash-order emulation / heap / DFS stack
 	int16_t h_next[MAXN];
 	int16_t h_before[Limits<MAXN>::kBuckets];
@@ -658,6 +660,528 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 	return GA_OK;
 }
 
+// =================================================================================================
+// Bands with cycles (GraphAligner.h:2362-2397).  Inside a strongly connected component a column
+// depends on itself through the cycle, so the reference relaxes the component's nodes off a work
+// stack and keeps, per column, how many of the 64 rows are already final ("confirmed"); a node's
+// stored minimum and the argmin list are whatever its LAST visit saw, so the visiting order and
+// the confirmation counts are part of the result.  This path therefore follows the reference's
+// own bit-vector form step by step: wave-uniform scalar code over the VP/VN words (the 64-bit
+// adds run on the scalar unit), with the cell-wise column merge done across the 64 lanes.  It is
+// compiled into the wide kernel variants only; a slice takes it when its band has a cycle.
+// =================================================================================================
+struct GCol { uint64_t vp, vn; int before; int rows; bool partial, exists; };
+
+GA_FN int gcol_end(const GCol& c) { return c.before + __builtin_popcountll(c.vp) - __builtin_popcountll(c.vn); }
+GA_FN bool conf_less(int ar, bool ap, int br, bool bp) { return ar < br || (ar == br && !ap && bp); }          // WordSlice.h:150-153
+GA_FN bool conf_greater(int ar, bool ap, int br, bool bp) { return ar > br || (ar == br && ap && !bp); }       // WordSlice.h:146-149
+GA_FN int bit_of(uint64_t w, int i) { return (int)((w >> (i & 63)) & 1); }
+
+// while a slice with cycles is being filled, end_cur[] holds rows | partial << 7 | exists << 8 per column
+GA_FN GCol gcol_load(const SliceRec& rec, const uint32_t* meta, uint32_t idx)
+{
+	GCol c;
+	c.vp = rec.vp[idx]; c.vn = rec.vn[idx]; c.before = rec.before[idx];
+	const uint32_t m = meta[idx];
+	c.rows = (int)(m & 127); c.partial = ((m >> 7) & 1) != 0; c.exists = ((m >> 8) & 1) != 0;
+	return c;
+}
+GA_FN void gcol_store(const SliceRec& rec, uint32_t* meta, uint32_t idx, const GCol& c)
+{
+	if (GA_LANE0)
+	{
+		rec.vp[idx] = c.vp; rec.vn[idx] = c.vn; rec.before[idx] = c.before;
+		meta[idx] = (uint32_t)c.rows | (c.partial ? 128u : 0u) | (c.exists ? 256u : 0u);
+	}
+}
+
+// one column step with row confirmation (getNextSlice, GraphAligner.h:1349-1427).  aboveEnd / aboveEnd2 = rows
+// j-1 / j-2 of the column to the left in the previous slice (only looked at when upLeftIn)
+GA_FN GCol gcol_step(uint64_t eq, GCol c, bool upIn, bool upLeftIn, bool diagIn, bool aboveEq, int aboveEnd, int aboveEnd2, int& status)
+{
+	const int oldBefore = c.before;
+	const int cr = c.rows;
+	const uint64_t atConfirmed = 1ull << (cr & 63);            // the reference shifts by 64 when everything is confirmed: x86 wraps
+	const uint64_t belowConfirmed = 1ull << ((cr - 1) & 63);
+	bool oneMore = false;
+	if (!c.exists || !diagIn) eq &= ~1ull;                      // :1358,1360
+	c.exists = upIn;
+	if (!upLeftIn) c.before += 1;
+	else
+	{
+		if (c.before > aboveEnd) status = GA_ASSERTION;         // :1366
+		const int viaDiagonal = aboveEnd2 + (aboveEq ? 0 : 1);
+		c.before = c.before + 1 < viaDiagonal ? c.before + 1 : viaDiagonal;
+	}
+	const int hin = c.before - oldBefore;
+	const uint64_t xv = eq | c.vn;
+	if (hin < 0) eq |= 1;
+	const uint64_t xh = (((eq & c.vp) + c.vp) ^ c.vp) | eq;
+	uint64_t ph = c.vn | ~(xh | c.vp);
+	uint64_t mh = c.vp & xh;
+	int diagDiff = hin;
+	if (cr > 0) diagDiff = ((ph & belowConfirmed) ? 1 : 0) - ((mh & belowConfirmed) ? 1 : 0);
+	if (cr > 0 && (mh & belowConfirmed)) oneMore = true;
+	else if (cr == 0 && hin == -1) oneMore = true;
+	if (c.partial && (~ph & atConfirmed)) oneMore = true;
+	ph <<= 1;
+	mh <<= 1;
+	if (hin < 0) mh |= 1; else if (hin > 0) ph |= 1;
+	c.vp = mh | ~(xv | ph);
+	c.vn = ph & xv;
+	diagDiff += ((c.vp & atConfirmed) ? 1 : 0) - ((c.vn & atConfirmed) ? 1 : 0);
+	if (diagDiff <= 0) oneMore = true;
+	else if (c.vn & atConfirmed) oneMore = true;
+	if (oneMore)
+	{
+		if (c.rows < W) c.rows += 1;
+		c.partial = false;
+	}
+	else if (!c.partial && c.rows < W) c.partial = true;
+	return c;
+}
+
+// index, in the sequence "VP bit of row i, then not-VN bit of row i" over rows [lo, hi), of the rank-th set
+// unit (BitPosition over the interleaved words, WordSlice.h:45-130,479-488); past the end -> 128 + excess
+GA_FN int interleaved_rank(uint64_t vp, uint64_t vn, int lo, int hi, int rank)
+{
+	int seen = 0;
+	for (int i = lo; i < hi; i++)
+	{
+		if (bit_of(vp, i)) { if (seen == rank) return 2 * i; seen++; }
+		if (!bit_of(vn, i)) { if (seen == rank) return 2 * i + 1; seen++; }
+	}
+	return 128 + (rank - seen);
+}
+
+// confirmed rows of the cell-wise minimum of two columns (WordSlice.h:423-510)
+GA_FN void merged_confirmation(GCol l, GCol r, int& rows, bool& partial, int& status)
+{
+	if (l.rows == r.rows && l.partial == r.partial) { rows = l.rows; partial = l.partial; return; }
+	if (conf_greater(r.rows, r.partial, l.rows, l.partial)) { GCol t = l; l = r; r = t; }
+	const uint64_t low = r.rows >= W ? ~0ull : ~(~0ull << r.rows);
+	int ls = l.before + __builtin_popcountll(l.vp & low) - __builtin_popcountll(l.vn & low);
+	int rs = r.before + __builtin_popcountll(r.vp & low) - __builtin_popcountll(r.vn & low);
+	if (r.rows == l.rows)
+	{
+		rs -= 1;
+		if (!bit_of(l.vp, l.rows)) ls -= 1;
+		rows = l.rows; partial = ls <= rs;
+		return;
+	}
+	ls += bit_of(l.vp, r.rows) - bit_of(l.vn, r.rows);
+	if (!(r.partial && bit_of(r.vp, r.rows))) rs -= 1;
+	if (ls == rs + 1) { rows = r.rows; partial = true; return; }
+	if (ls > rs + 1) { rows = r.rows; partial = r.partial; return; }
+	if (l.rows > r.rows + 1)
+	{
+		if (ls > rs) status = GA_ASSERTION;
+		const int lo = r.rows + 1, hi = l.rows;
+		const int p = interleaved_rank(l.vp, l.vn, lo, hi, rs - ls);
+		if (p / 2 < l.rows)
+		{
+			const int q = interleaved_rank(l.vp, l.vn, lo, hi, rs - ls + 1);
+			rows = p / 2; partial = q / 2 > p / 2;
+			return;
+		}
+		const uint64_t span = (hi >= W ? ~0ull : ~(~0ull << hi)) & (~0ull << lo);
+		ls += __builtin_popcountll(l.vp & span) - __builtin_popcountll(l.vn & span);
+		rs -= l.rows - r.rows - 1;
+	}
+	rows = l.rows; partial = l.partial;
+	if (!l.partial) return;
+	rs -= 1;
+	if (bit_of(l.vp, l.rows) && !(ls <= rs)) partial = false;
+}
+
+// cell-wise minimum of two columns over rows j-1 .. j+63 (mergeTwoSlices, WordSlice.h:361-421): lanes = rows
+GA_FN GCol gcol_merge(GCol a, GCol b, const VU& lowMask, int& status)
+{
+	if (a.before > b.before) { GCol t = a; a = b; b = t; }
+	GCol out;
+	merged_confirmation(a, b, out.rows, out.partial, status);
+	const VI sa = vpopc(a.vp & lowMask) - vpopc(a.vn & lowMask) + a.before;
+	const VI sb = vpopc(b.vp & lowMask) - vpopc(b.vn & lowMask) + b.before;
+	const VI m = vmin(sa, sb);
+	const VI up = shr1(m, a.before);
+	out.vp = ballot(m == up + 1);
+	out.vn = ballot(m == up - 1);
+	out.before = a.before;
+	out.exists = a.before < b.before ? a.exists : (a.exists || b.exists);    // :398-409
+	return out;
+}
+
+// ---- Tarjan over the band subgraph with components (GraphAligner.h:1751-1901): post[] = emission order,
+// comp[slot] = component number in emission order
+template <int MAXN> GA_FN int scc_order(const GaDevGraph& g, WaveState<MAXN>& ws, int cn, int& nComps)
+{
+	for (int c = 0; c < cn; c += LANES) store_lanes(ws.color + c, cn - c, VI(0));
+	wave_order();
+	int16_t* index = ws.h_next;
+	int16_t* tstack = ws.h_order;
+	int emitted = 0, counter = 0, tsp = 0;
+	nComps = 0;
+	for (int root = 0; root < cn; root++)
+	{
+		if (ws.color[root] != 0) continue;
+		int sp = 0;
+		auto open = [&](int v) {
+			ws.color[v] = 1;                                   // on the component stack
+			index[v] = (int16_t)counter; ws.low[v] = (int16_t)counter; counter++;
+			tstack[tsp++] = (int16_t)v;
+			ws.st_slot[sp] = (int16_t)v; ws.st_cur[sp] = 0; sp++;
+		};
+		open(root);
+		while (sp > 0)
+		{
+			const int v = ws.st_slot[sp - 1];
+			const int cur = (int)ws.st_cur[sp - 1];
+			if (cur < out_degree(g, ws, v))
+			{
+				const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, v, cur));
+				if (x >= 0 && ws.color[x] == 0) { open(x); continue; }
+				if (x >= 0 && ws.color[x] == 1 && index[x] < ws.low[v]) ws.low[v] = index[x];
+				ws.st_cur[sp - 1] = (uint32_t)(cur + 1);
+				continue;
+			}
+			sp--;
+			if (ws.low[v] == index[v])
+			{
+				int back;
+				do
+				{
+					back = tstack[--tsp];
+					ws.color[back] = 2;
+					ws.comp[back] = (int16_t)nComps;
+					ws.post[emitted++] = (int16_t)back;
+				} while (back != v);
+				nComps++;
+			}
+			if (sp > 0)
+			{
+				const int parent = ws.st_slot[sp - 1];
+				if (ws.low[v] < ws.low[parent]) ws.low[parent] = ws.low[v];
+				ws.st_cur[sp - 1] += 1;
+			}
+		}
+	}
+	return GA_OK;
+}
+
+// ---- exact row j-1 of one component (forceComponentZeroRow, GraphAligner.h:1903-1995): shortest paths from the
+// columns fed from outside the component; lanes = columns along a node
+template <int MAXN>
+GA_FN int zero_row_component(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, int pn, int cn, int lo, int hi, int ci)
+{
+	const VI lane = lane_iota();
+	int heapSize = 0;
+	for (int k = lo; k < hi; k++)
+	{
+		const int s = ws.post[k];
+		const uint32_t len = ws.cn_len[s];
+		const int ps = ws.cn_prev[s];
+		const bool inPrev = ps >= 0;
+		const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
+		const uint32_t outBase = ws.cn_colBase[s];
+		int zero0 = inPrev ? (int)(pend[0] >> 2) : INF;
+		const int inDeg = in_degree(g, ws, s);
+		for (int e = 0; e < inDeg; e++)
+		{
+			const uint32_t m = in_neighbor(g, ws, s, e);
+			const int cs = find_slot(ws.cn_node, cn, m);
+			const int pm = find_slot(ws.pn_node, pn, m);
+			if (cs < 0 && pm < 0) continue;
+			if (cs >= 0 && ws.comp[cs] == ci) continue;
+			if (cs >= 0) zero0 = zero0 < ws.cn_lastBefore[cs] + 1 ? zero0 : ws.cn_lastBefore[cs] + 1;
+			if (pm >= 0) zero0 = zero0 < ws.pn_lastEnd[pm] + 1 ? zero0 : ws.pn_lastEnd[pm] + 1;
+		}
+		int carry = INF;
+		for (uint32_t w0 = 0; w0 < len; w0 += LANES)
+		{
+			const int n = (int)(len - w0 < (uint32_t)LANES ? len - w0 : (uint32_t)LANES);
+			VI zeroV = VI(INF);
+			if (zero0 != INF)
+			{
+				const VB live = lane < n;
+				const VI pendV = inPrev ? select(live, load_lanes(pend + w0, n, 0) >> 2, VI(INF)) : VI(INF);
+				const VI zin = w0 == 0 ? select(lane == 0, VI(zero0), pendV) : pendV;
+				zeroV = vmin(prefix_min(zin - lane) + lane, w0 == 0 ? VI(INF) : lane + (carry + 1));
+				carry = read_lane(zeroV, n - 1);
+			}
+			store_lanes(rec.before + outBase + w0, n, zeroV);
+		}
+		if (zero0 == INF) continue;
+		const int outDeg = out_degree(g, ws, s);
+		for (int e = 0; e < outDeg; e++)
+		{
+			const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, s, e));
+			if (x < 0 || ws.comp[x] != ci) continue;
+			if (!heap_push(ws, heapSize, (uint32_t)x, carry + 1)) return GA_CAP_HEAP;
+		}
+	}
+	wave_sync();
+	while (heapSize > 0)
+	{
+		const int s = (int)ws.heap_node[0];
+		const int score = ws.heap_prio[0];
+		heap_pop(ws, heapSize);
+		const uint32_t len = ws.cn_len[s];
+		const uint32_t outBase = ws.cn_colBase[s];
+		bool reachedEnd = true;
+		for (uint32_t w0 = 0; w0 < len && reachedEnd; w0 += LANES)
+		{
+			const int n = (int)(len - w0 < (uint32_t)LANES ? len - w0 : (uint32_t)LANES);
+			const VI have = load_lanes(rec.before + outBase + w0, n, 0);
+			const VI cand = lane + (score + (int)w0);
+			const uint64_t stop = ballot((lane < n) && (have < cand + 1));
+			const int upto = stop ? ctz64(stop) : n;
+			store_lanes(rec.before + outBase + w0, upto, cand);
+			if (stop) reachedEnd = false;
+		}
+		wave_sync();
+		if (!reachedEnd) continue;
+		const int outDeg = out_degree(g, ws, s);
+		for (int e = 0; e < outDeg; e++)
+		{
+			const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, s, e));
+			if (x < 0 || ws.comp[x] != ci) continue;
+			if (!heap_push(ws, heapSize, (uint32_t)x, score + (int)len)) return GA_CAP_HEAP;
+		}
+	}
+	// every column restarts as an unconfirmed vertical run under its exact row j-1 score (:1975-1993)
+	for (int k = lo; k < hi; k++)
+	{
+		const int s = ws.post[k];
+		const uint32_t len = ws.cn_len[s];
+		const int ps = ws.cn_prev[s];
+		const bool inPrev = ps >= 0;
+		const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
+		const uint32_t outBase = ws.cn_colBase[s];
+		int last = INF;
+		for (uint32_t w0 = 0; w0 < len; w0 += LANES)
+		{
+			const int n = (int)(len - w0 < (uint32_t)LANES ? len - w0 : (uint32_t)LANES);
+			const VI b = load_lanes(rec.before + outBase + w0, n, 0);
+			if (ballot((lane < n) && (b == INF))) return GA_ASSERTION;
+			const VI pendV = inPrev ? (load_lanes(pend + w0, n, 0) >> 2) : VI(-1);
+			store_lanes(rec.vp + outBase + w0, n, VU(~0ull));
+			store_lanes(rec.vn + outBase + w0, n, VU(0ull));
+			store_lanes(slot.end_cur + outBase + w0, n, select(pendV == b, VI(256), VI(0)));
+			last = read_lane(b, n - 1);
+		}
+		if (GA_LANE0) ws.cn_lastBefore[s] = last;
+	}
+	wave_sync();
+	return GA_OK;
+}
+
+// ---- one visit of one node (calculateNode, GraphAligner.h:1457-1573) -----------------------------------------------
+// callMin / callLast: minimum scoreEnd over the fully confirmed columns this visit touched and the last such column
+template <int MAXN>
+GA_FN int fill_node_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const uint64_t* eqOf, const VI& rowCode,
+                            int rawAbove, uint32_t nRows, uint32_t j, int prevMin, int pn, int cn, int s, int& callMin, uint32_t& callLast)
+{
+	const VU lowMask = low_mask_through_lane();
+	int status = GA_OK;
+	callMin = INF;
+	callLast = 0;
+	const uint32_t len = ws.cn_len[s];
+	const uint64_t firstCol = ((uint64_t)ws.cn_startHi[s] << 32) | ws.cn_startLo[s];
+	const int ps = ws.cn_prev[s];
+	const bool inPrev = ps >= 0;
+	const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
+	const uint32_t outBase = ws.cn_colBase[s];
+	uint32_t* meta = slot.end_cur;
+	const bool aboveAlways = j == 0 && inPrev;
+	auto aboveEqAt = [&](int base) { return aboveAlways || (j > 0 && rawAbove == base); };
+	auto note = [&](const GCol& c, uint32_t w) {
+		if (c.rows != W) return;
+		const int end = gcol_end(c);
+		if (end < callMin) { callMin = end; callLast = w; }
+		else if (end == callMin) callLast = w;
+	};
+	auto verticalEntry = [&](GCol& c, uint32_t w) {
+		// re-entry from the cell above when that beats what came from the left (:1504-1509, 1541-1546)
+		if (!inPrev) return;
+		const int oEnd = (int)(pend[w] >> 2);
+		if (c.before > oEnd)
+		{
+			GCol src;
+			src.vp = ~0ull; src.vn = 0; src.before = oEnd; src.rows = W; src.partial = false; src.exists = true;
+			c = gcol_merge(c, src, lowMask, status);
+		}
+	};
+	auto sanity = [&](const GCol& c, uint32_t w) {
+		// assertSliceCorrectness (:1437-1455)
+		const int end = gcol_end(c);
+		if (c.before < 0 || end < 0 || (c.vp & c.vn) != 0) status = GA_ASSERTION;
+		if (inPrev && c.before > (int)(pend[w] >> 2)) status = GA_ASSERTION;
+		if (c.rows == W && (end < prevMin || c.before < prevMin)) status = GA_ASSERTION;
+	};
+
+	GCol mine = gcol_load(rec, meta, outBase);
+	const int rows0 = mine.rows;
+	const bool partial0 = mine.partial;
+	if (rows0 == W) return GA_OK;
+	const int base0 = g_base(g, firstCol);
+	const int inDeg = in_degree(g, ws, s);
+	bool source = true;
+	for (int e = 0; e < inDeg; e++)
+	{
+		const uint32_t m = in_neighbor(g, ws, s, e);
+		if (find_slot(ws.cn_node, cn, m) >= 0 || find_slot(ws.pn_node, pn, m) >= 0) { source = false; break; }
+	}
+	GCol c;
+	if (source)
+	{
+		// :1317-1337
+		c.vn = 0; c.rows = W; c.partial = false;
+		if (j == 0 && inPrev)
+		{
+			const uint64_t firstVp = (eqOf[base0] & 1) ? 0 : 1;
+			c.vp = (~0ull & ~1ull) | firstVp; c.before = (int)(pend[0] >> 2); c.exists = true;
+		}
+		else if (inPrev) { c.vp = ~0ull; c.before = (int)(pend[0] >> 2); c.exists = true; }
+		else { c.vp = ~0ull & ~1ull; c.before = (int)(nRows + 1); c.exists = false; }
+	}
+	else
+	{
+		// first column from the in-neighbours' last columns (:1270-1315)
+		bool any = false;
+		const bool aboveEq0 = aboveEqAt(base0);
+		for (int e = 0; e < inDeg; e++)
+		{
+			const uint32_t m = in_neighbor(g, ws, s, e);
+			const int cs = find_slot(ws.cn_node, cn, m);
+			const int pm = find_slot(ws.pn_node, pn, m);
+			if (cs < 0 && pm < 0) continue;
+			uint64_t eqHere = eqOf[base0];
+			const bool haveAbove = pm >= 0;
+			GCol left;
+			if (cs >= 0) left = gcol_load(rec, meta, ws.cn_colBase[cs] + ws.cn_len[cs] - 1);
+			else
+			{
+				left.vp = ~0ull; left.vn = 0; left.before = ws.pn_lastEnd[pm]; left.rows = W; left.partial = false; left.exists = true;
+				eqHere &= 1;                                                         // :1294-1301
+			}
+			const GCol here = gcol_step(eqHere, left, mine.exists, mine.exists && haveAbove, haveAbove, aboveEq0,
+			                            haveAbove ? ws.pn_lastEnd[pm] : 0, haveAbove ? ws.pn_lastEnd2[pm] : 0, status);
+			if (!any) { c = here; any = true; }
+			else c = gcol_merge(c, here, lowMask, status);
+		}
+		if (!any) return GA_ASSERTION;
+		verticalEntry(c, 0);
+	}
+	note(c, 0);
+	sanity(c, 0);
+	gcol_store(rec, meta, outBase, c);
+	if (conf_less(c.rows, c.partial, rows0, partial0)) status = GA_ASSERTION;
+	if (status != GA_OK) return status;
+	if (c.rows == rows0 && c.partial == partial0) { wave_sync(); return GA_OK; }
+	for (uint32_t w = 1; w < len; w++)
+	{
+		const GCol was = gcol_load(rec, meta, outBase + w);
+		if (was.rows == W) break;
+		const int base = g_base(g, firstCol + w);
+		const bool e = was.exists;
+		const int leftBefore = c.before;
+		int aboveEnd = 0, aboveEnd2 = 0;
+		if (inPrev) { const uint32_t pr = pend[w - 1]; aboveEnd = (int)(pr >> 2); aboveEnd2 = aboveEnd - (int)(pr & 1) + (int)((pr >> 1) & 1); }
+		c = gcol_step(eqOf[base], c, e, e, c.exists, aboveEqAt(base), aboveEnd, aboveEnd2, status);
+		verticalEntry(c, w);
+		if (!(inPrev || c.before == (int)j || c.before == leftBefore + 1)) status = GA_ASSERTION;    // :1548
+		sanity(c, w);
+		note(c, w);
+		gcol_store(rec, meta, outBase + w, c);
+		if (status != GA_OK) return status;
+		if (c.rows == was.rows && c.partial == was.partial) break;
+	}
+	(void)rowCode;
+	wave_sync();
+	return status;
+}
+
+// ---- one slice whose band has a cycle (calculateSlice, GraphAligner.h:2331-2451) ---------------------------------
+template <int MAXN>
+GA_FN int fill_slice_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot, const SliceRec& rec, const VI rowCode, const int rowAboveCode,
+                             uint32_t nRows, uint32_t j, int prevMin, int pn, int cn, int nComps, int& sliceMin, int& minSlot, uint32_t& minOffset)
+{
+	const VI lane = lane_iota();
+	if (ballot((rowCode & GA_ROW_INVALID) != 0)) return GA_ASSERTION;
+	const int rawAbove = j > 0 ? (rowAboveCode >> 4) & 7 : 7;
+	uint64_t eqOf[4];
+	for (int b = 0; b < 4; b++) eqOf[b] = ballot(bit_extract(rowCode, b) != 0);
+	sliceMin = INF;
+	minSlot = -1;
+	minOffset = 0;
+	int hi = cn;
+	for (int ci = nComps - 1; ci >= 0; ci--)
+	{
+		int lo = hi;
+		while (lo > 0 && ws.comp[ws.post[lo - 1]] == ci) lo--;
+		int status = zero_row_component(g, ws, slot, rec, pn, cn, lo, hi, ci);
+		if (status != GA_OK) return status;
+		// the work stack (UniqueQueue): color[] = "is on the stack"
+		int sp = 0;
+		for (int k = lo; k < hi; k++) { const int s = ws.post[k]; ws.st_slot[sp++] = (int16_t)s; ws.color[s] = 1; }
+		while (sp > 0)
+		{
+			const int s = ws.st_slot[--sp];
+			ws.color[s] = 0;
+			const uint32_t lastIdx = ws.cn_colBase[s] + ws.cn_len[s] - 1;
+			const GCol oldEnd = gcol_load(rec, slot.end_cur, lastIdx);
+			int callMin;
+			uint32_t callLast;
+			status = fill_node_general(g, ws, slot, rec, eqOf, rowCode, rawAbove, nRows, j, prevMin, pn, cn, s, callMin, callLast);
+			if (status != GA_OK) return status;
+			if (GA_LANE0) ws.cn_min[s] = callMin;
+			const GCol newEnd = gcol_load(rec, slot.end_cur, lastIdx);
+			if (newEnd.before != oldEnd.before) return GA_ASSERTION;                                       // :2385
+			if (conf_less(newEnd.rows, newEnd.partial, oldEnd.rows, oldEnd.partial)) return GA_ASSERTION;  // :2386
+			if (newEnd.before < (int)nRows && conf_greater(newEnd.rows, newEnd.partial, oldEnd.rows, oldEnd.partial))
+			{
+				const int outDeg = out_degree(g, ws, s);
+				for (int e = 0; e < outDeg; e++)
+				{
+					const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, s, e));
+					if (x < 0 || ws.comp[x] != ci || ws.color[x] != 0) continue;
+					if ((slot.end_cur[ws.cn_colBase[x]] & 127) < (uint32_t)W) { ws.st_slot[sp++] = (int16_t)x; ws.color[x] = 1; }
+				}
+			}
+			if (callMin != INF && callMin <= sliceMin) { sliceMin = callMin; minSlot = s; minOffset = callLast; }
+		}
+		for (int k = lo; k < hi; k++)
+			if ((slot.end_cur[ws.cn_colBase[ws.post[k]]] & 127) != (uint32_t)W) return GA_ASSERTION;      // :2422-2425
+		hi = lo;
+	}
+	// ---- leave the slice in the form the next slice and the traceback read ----
+	for (int s = 0; s < cn; s++)
+	{
+		const uint32_t len = ws.cn_len[s];
+		const uint32_t outBase = ws.cn_colBase[s];
+		uint64_t vp = 0, vn = 0;
+		int before = 0, end = 0;
+		for (uint32_t w0 = 0; w0 < len; w0 += LANES)
+		{
+			const int n = (int)(len - w0 < (uint32_t)LANES ? len - w0 : (uint32_t)LANES);
+			const VU vpV = load_lanes_u64(rec.vp + outBase + w0, n), vnV = load_lanes_u64(rec.vn + outBase + w0, n);
+			const VI beforeV = load_lanes(rec.before + outBase + w0, n, 0);
+			const VI endV = beforeV + vpopc(vpV) - vpopc(vnV);
+			const VI packedV = (endV << 2) | vpopc(vpV & VU(1ull << 63)) | (vpopc(vnV & VU(1ull << 63)) << 1);
+			store_lanes(slot.end_cur + outBase + w0, n, packedV);
+			vp = read_lane(vpV, n - 1); vn = read_lane(vnV, n - 1);
+			before = read_lane(beforeV, n - 1); end = read_lane(endV, n - 1);
+		}
+		if (GA_LANE0)
+		{
+			ws.cn_lastVP[s] = vp; ws.cn_lastVN[s] = vn; ws.cn_lastBefore[s] = before; ws.cn_lastExists[s] = 0;
+			ws.cn_lastEnd[s] = end; ws.cn_lastEnd2[s] = end - (int)(vp >> 63) + (int)(vn >> 63);
+		}
+	}
+	(void)lane;
+	return GA_OK;
+}
+
 // ---- cell value from the stored words (WordSlice.h:223-229; getValueOrMax GraphAligner.h:2008-2017) ------
 struct SliceView { const uint32_t* arena; const uint32_t* slice_off; };
 
@@ -732,6 +1256,14 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		if (slice + 1 < numSlices) rowNext = load_lanes(rows + (slice + 1) * W, W, 0);
 		GA_LAP(2);
 		status = processing_order(g, ws, cn);
+		int nComps = 0;
+		bool cyclicBand = false;
+		if constexpr (MAXN > 32)
+		{
+			// a band with a cycle is filled by the confirmation-tracking path (wide kernel variants only; the
+			// narrow variant reports GA_UNSUPPORTED_CYCLE and the job is rerun by a wide one)
+			if (status == GA_UNSUPPORTED_CYCLE) { wave_order(); status = scc_order(g, ws, cn, nComps); cyclicBand = true; }
+		}
 		GA_LAP(3);
 		if (status != GA_OK) break;
 		uint64_t need = slice_words((uint32_t)cn, totalCols);
@@ -746,7 +1278,12 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		int sliceMin, minSlot;
 		uint32_t minOffset;
 		GA_LAP(0);
-		status = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
+		if constexpr (MAXN > 32)
+		{
+			if (cyclicBand) status = fill_slice_general(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, prevMin, pn, cn, nComps, sliceMin, minSlot, minOffset);
+			else status = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
+		}
+		else status = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
 		rowAboveCode = read_lane(rowCode, W - 1);
 		GA_LAP(4);
 		if (status != GA_OK) break;

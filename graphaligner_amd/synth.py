@@ -308,3 +308,74 @@ def linear_graph(n, node_len=64, seed=42):
 def bubble_graph(n, node_len=64, seed=44, snp_every=100, indel_every=1000, sv_every=50000):
     """yeast-like pangenome: SNP / short-indel / SV bubbles"""
     return SynthGraph(random_genome(n, seed), node_len=node_len, snp_every=snp_every, indel_every=indel_every, sv_every=sv_every, seed=seed + 1)
+
+
+# ---- graphs with cycles (tandem repeats, self loops) -----------------------------------------------
+def cyclic_graph(n, node_len=16, seed=7, back_edges=6, self_loops=2, max_span=6, snp_every=60):
+    """a variation graph plus `back_edges` edges from a node to one of the `max_span` nodes before
+    it (a tandem repeat unit) and `self_loops` nodes that follow themselves (a homopolymer-like
+    repeat): the band subgraph of a slice crossing them has strongly connected components"""
+    rng = np.random.default_rng(seed + 1000)
+    g = SynthGraph(random_genome(n, seed), node_len=node_len, snp_every=snp_every, seed=seed)
+    ids = [i for i, _ in g.nodes]
+    have = set((f, t) for f, _, t, _ in g.edges)
+    for _ in range(back_edges):
+        a = int(rng.integers(max_span + 1, len(ids) - 2))
+        b = a - int(rng.integers(1, max_span + 1))
+        if (ids[a], ids[b]) not in have:
+            have.add((ids[a], ids[b]))
+            g.edges.append((ids[a], False, ids[b], False))
+    for _ in range(self_loops):
+        a = int(rng.integers(2, len(ids) - 2))
+        if (ids[a], ids[a]) not in have:
+            have.add((ids[a], ids[a]))
+            g.edges.append((ids[a], False, ids[a], False))
+    return g
+
+
+def walk_reads(graph, n_reads, length, sub=0.03, ins=0.03, dele=0.03, seed=1, both_strands=True, mid_seed=False, first_nodes=None):
+    """reads spelled by random walks along the forward edges (so repeats are traversed a random
+    number of times), with SimulateReads-style errors; seeds as in simulate_reads"""
+    rng = np.random.default_rng(seed)
+    seq = dict(graph.nodes)
+    out = {}
+    for f, _, t, _ in graph.edges:
+        out.setdefault(f, []).append(t)
+    ids = [i for i, _ in graph.nodes]
+    limit = first_nodes if first_nodes is not None else max(1, len(ids) // 2)
+    reads, seeds = [], []
+    attempts = 0
+    while len(reads) < n_reads:
+        attempts += 1
+        if attempts > 50 * n_reads + 1000:
+            raise RuntimeError("walk_reads: cannot place %d reads of %d bp" % (n_reads, length))
+        cur = ids[int(rng.integers(0, limit))]
+        path, total = [], 0
+        while total < length and cur is not None:
+            path.append(cur)
+            total += len(seq[cur])
+            nxt = out.get(cur)
+            cur = nxt[int(rng.integers(len(nxt)))] if nxt else None
+        if total < length or len(path) < 3:
+            continue
+        as_bytes = lambda nodes: np.frombuffer("".join(seq[x] for x in nodes).encode(), dtype=np.uint8)
+        k = len(path) // 2 if mid_seed else 0
+        reverse = both_strands and rng.random() < 0.5
+        if not reverse:
+            a = add_errors(as_bytes(path[:k]), sub, ins, dele, rng) if k else np.zeros(0, dtype=np.uint8)
+            b = add_errors(as_bytes(path[k:]), sub, ins, dele, rng)
+            if len(b) < 2 or (k and len(a) < 2):
+                continue
+            reads.append(np.concatenate([a, b]).tobytes().decode())
+            seeds.append((int(path[k]), len(a), False))
+        else:
+            # the reverse read starts with the reverse complement of the walk's tail
+            k = len(path) // 2 if mid_seed else len(path) - 1
+            tail = path[k + 1:]
+            a = add_errors(revcomp_bytes(as_bytes(tail)), sub, ins, dele, rng) if tail else np.zeros(0, dtype=np.uint8)
+            b = add_errors(revcomp_bytes(as_bytes(path[:k + 1])), sub, ins, dele, rng)
+            if len(b) < 2 or (tail and len(a) < 2):
+                continue
+            reads.append(np.concatenate([a, b]).tobytes().decode())
+            seeds.append((int(path[k]), len(a), True))
+    return reads, seeds

@@ -63,9 +63,9 @@ struct EmulBatch : GaBackendBatch
 		{
 			uint32_t slices = jobs[j].n_rows / 64;
 			// deliberately small first-try capacities so the retry path is exercised too
-			runOne<64>(j, 2048, 64 + (uint64_t)slices * (6 + 2 * 40 + 5 * 700), jobs[j].n_rows * 2 + 512);
+			runOne<32>(j, 2048, 64 + (uint64_t)slices * (6 + 2 * 40 + 5 * 700), jobs[j].n_rows * 2 + 512);
 			int s = outs[j].status;
-			if (s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP)
+			if (s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP || s == GA_UNSUPPORTED_CYCLE)
 			{
 				retried++;
 				runOne<256>(j, 200000, 64 + (uint64_t)slices * (6 + 2 * 256 + 5 * 20000), jobs[j].n_rows * 8 + 4096);

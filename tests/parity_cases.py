@@ -33,6 +33,29 @@ def case_random_graphs(node_len, snp, indel, sv, lib_path=None):
         assert n_cmp >= len(reads) // 2
 
 
+CYCLIC_GRAPHS = [(4, 10, 6, 1, 2), (8, 35, 8, 2, 5), (16, 35, 5, 3, 3), (32, 80, 9, 0, 8), (12, 35, 12, 2, 1)]
+
+
+def case_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span, lib_path=None):
+    """bands with strongly connected components (tandem-repeat back edges, self loops): the
+    reference relaxes such components with row confirmation (GraphAligner.h:2362-2397); node
+    minima, band choice and the trace start depend on the visiting order, so only a faithful
+    restatement passes.  Reads are random walks that go round the repeats."""
+    g = synth.cyclic_graph(5000, node_len=node_len, seed=node_len + bw, back_edges=back_edges, self_loops=self_loops, max_span=max_span)
+    n_ok = n_cyclic_jobs = 0
+    for length, mid in [(400, False), (900, True), (1800, False), (1800, True)]:
+        reads, seeds = synth.walk_reads(g, 8, length, seed=length + node_len, mid_seed=mid, first_nodes=max(1, len(g.nodes) // 3))
+        devs, oras = pc.check_parity(g.nodes, g.edges, reads, seeds, bw, lib_path=lib_path, ctx="cyclic nl%d bw%d len%d" % (node_len, bw, length))
+        n_ok += sum(1 for d in devs if d["status"] == 0 and not d["failed"])
+        # the same batch again through the batch interface: the jobs must have needed the wide (cycle-capable) variant
+        gg = binding.Graph(g.nodes, g.edges, lib_path=lib_path)
+        b = gg.prepare(reads, seeds, bw)
+        b.run()
+        n_cyclic_jobs += b.stats()["jobs_retried"]
+    assert n_ok >= 16, n_ok
+    assert n_cyclic_jobs > 0
+
+
 def case_short_and_edge_reads(lib_path=None):
     """directions shorter than 193 bp hit assert(samplingFrequency > 1) in the reference
     (GraphAligner.h:906); seeds at the last base align backwards only (:3006)"""

@@ -22,6 +22,11 @@ def test_random_graphs(lib, node_len, snp, indel, sv):
     cases.case_random_graphs(node_len, snp, indel, sv, lib)
 
 
+@pytest.mark.parametrize("node_len,bw,back_edges,self_loops,max_span", cases.CYCLIC_GRAPHS)
+def test_cyclic_graphs(lib, node_len, bw, back_edges, self_loops, max_span):
+    cases.case_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span, lib)
+
+
 def test_short_and_edge_reads(lib):
     cases.case_short_and_edge_reads(lib)
 

@@ -24,6 +24,11 @@ def test_random_graphs(node_len, snp, indel, sv):
     cases.case_random_graphs(node_len, snp, indel, sv)
 
 
+@pytest.mark.parametrize("node_len,bw,back_edges,self_loops,max_span", cases.CYCLIC_GRAPHS)
+def test_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span):
+    cases.case_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span)
+
+
 def test_short_and_edge_reads():
     cases.case_short_and_edge_reads()
 
