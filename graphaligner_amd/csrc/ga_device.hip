@@ -21,7 +21,7 @@ namespace {
 
 struct SlotLayout
 {
-	uint64_t endPrev, endCur, sliceOff, arena, trace, flags, bytes;
+	uint64_t endPrev, endCur, sliceOff, arena, trace, flags, ckpt, belowOff, bytes;
 };
 __host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxSlices, uint64_t arenaWords, uint32_t traceCap)
 {
@@ -34,6 +34,8 @@ __host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxS
 	l.arena = at; at = up(at + 4ull * arenaWords);
 	l.trace = at; at = up(at + 1ull * traceCap + 64);
 	l.flags = at; at = up(at + maxSlices + 1);
+	l.ckpt = at; at = up(at + 4ull * (maxSlices + 2));
+	l.belowOff = at; at = up(at + 4ull * (maxSlices + 1));
 	l.bytes = at;
 	return l;
 }
@@ -41,7 +43,7 @@ __host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxS
 #ifndef GA_WAVES_EU
 #define GA_WAVES_EU 4
 #endif
-template <int MAXN>
+template <int MAXN, bool GENERAL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GA_WAVES_EU, 8))) ga_extend_kernel(GaLaunch L)
 {
 	__shared__ gak::WaveState<MAXN> ws;
@@ -54,12 +56,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GA_WAVE
 	slot.arena = (uint32_t*)(base + lay.arena);
 	slot.trace = base + lay.trace;
 	slot.slice_flags = base + lay.flags;
+	slot.ckpt = (uint32_t*)(base + lay.ckpt);
+	slot.below_off = (uint32_t*)(base + lay.belowOff);
 	while (true)
 	{
 		uint32_t k = gaw::wave_atomic_add(L.next_job, 1u);
 		if (k >= L.n_jobs) break;                      // every wave reaches this exit once the queue is drained
 		uint32_t job = L.job_list ? L.job_list[k] : k;
-		gak::run_job<MAXN>(L, ws, slot, job);
+		gak::run_job<MAXN, GENERAL>(L, ws, slot, job);
 		__syncthreads();
 	}
 }
@@ -152,7 +156,7 @@ struct DevBatch : GaBackendBatch
 		// anything wider fails with a capacity status and is rerun by the wide variant
 		L.cap_cols = 4096;
 		L.trace_cap = cfg.max_rows * 2 + 1024;
-		L.arena_words = 64 + (uint64_t)L.max_slices * (gak::kSliceHdrWords + 2 * 64 + 5 * 800);
+		L.arena_words = 64 + (uint64_t)L.max_slices * (gak::kSliceHdrWords + 3 * 64 + 5 * 800);
 		SlotLayout lay = slotLayout(L.cap_cols, L.max_slices, L.arena_words, L.trace_cap);
 		L.slot_bytes = lay.bytes;
 		size_t freeB = 0, totalB = 0;
@@ -184,8 +188,8 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipMemsetAsync(L.next_job, 0, 16, stream));
 		HIP_OK(hipMemsetAsync(L.trace_top, 0, 16, stream));
 		HIP_OK(hipEventRecord(evStart, stream));
-		if (narrow) hipLaunchKernelGGL(ga_extend_kernel<32>, dim3(slots), dim3(64), 0, stream, L);
-		else hipLaunchKernelGGL(ga_extend_kernel<64>, dim3(slots), dim3(64), 0, stream, L);
+		if (narrow) hipLaunchKernelGGL((ga_extend_kernel<32, false>), dim3(slots), dim3(64), 0, stream, L);
+		else hipLaunchKernelGGL((ga_extend_kernel<64, false>), dim3(slots), dim3(64), 0, stream, L);
 		HIP_OK(hipGetLastError());
 		HIP_OK(hipEventRecord(evStop, stream));
 		outs.resize(jobs.size());
@@ -195,21 +199,25 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipEventElapsedTime(&ms, evStart, evStop));
 		st.kernel_ms = ms;
 		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
-		// ---- capacity misses climb a ladder of wider variants: 64 band nodes in LDS, then 256 with large buffers ----
+		// ---- what the lean variant could not finish climbs a ladder: 64 band nodes in LDS; then the general variants, which
+		// also carry the paths for bands with cycles and for ramp redos; last 256 band nodes with large buffers ----
 		st.jobs_retried = 0;
-		int rc = retryPass<64>(8192, 2 * 64 + 5 * 2048, 3, 12);
+		int rc = retryPass<64, false>(8192, 3 * 64 + 5 * 2048, 3, 12, false);
 		if (rc) return rc;
-		rc = retryPass<256>(65536, 2 * 256 + 5 * 8192, 6, 4);
+		rc = retryPass<64, true>(8192, 3 * 64 + 5 * 4096, 4, 8, true);
+		if (rc) return rc;
+		rc = retryPass<256, true>(65536, 3 * 256 + 5 * 8192, 6, 4, true);
 		return rc;
 	}
 
-	// statuses a wider kernel variant can resolve: capacity misses, and bands with cycles (only the wide variants carry that path)
-	static bool isCapacity(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP || s == GA_UNSUPPORTED_CYCLE; }
+	static bool isCapacity(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; }
+	// bands with cycles and ramp redos: only the general variants carry those paths
+	static bool needsGeneral(int s) { return s == GA_UNSUPPORTED_CYCLE || s == GA_UNSUPPORTED_RAMP; }
 
-	template <int MAXN> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry)
+	template <int MAXN, bool GENERAL> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry, bool general)
 	{
 		std::vector<uint32_t> again;
-		for (uint32_t i = 0; i < outs.size(); i++) if (isCapacity(outs[i].status)) again.push_back(i);
+		for (uint32_t i = 0; i < outs.size(); i++) if (isCapacity(outs[i].status) || (general && needsGeneral(outs[i].status))) again.push_back(i);
 		if (again.empty()) return 0;
 		st.jobs_retried += again.size();
 		GaLaunch R = L;
@@ -244,7 +252,7 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipEventCreate(&a));
 		HIP_OK(hipEventCreate(&b));
 		HIP_OK(hipEventRecord(a, stream));
-		hipLaunchKernelGGL(ga_extend_kernel<MAXN>, dim3(rslots), dim3(64), 0, stream, R);
+		hipLaunchKernelGGL((ga_extend_kernel<MAXN, GENERAL>), dim3(rslots), dim3(64), 0, stream, R);
 		HIP_OK(hipGetLastError());
 		HIP_OK(hipEventRecord(b, stream));
 		HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));

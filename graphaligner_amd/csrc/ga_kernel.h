@@ -25,7 +25,7 @@ using namespace gaw;
 
 constexpr int W = 64;
 constexpr uint32_t kCutoff = 200000;         // GraphAlignerCommon.h:10
-constexpr int kSliceHdrWords = 6;
+constexpr int kSliceHdrWords = 12;          // nNodes, nCols, minScore, minSlot, minOffset, flags, logCorrect(2), logWrong(2), slice, reserved
 #ifndef GA_TWO_STAGE_SCAN
 #define GA_TWO_STAGE_SCAN 0
 #endif
@@ -91,6 +91,8 @@ struct Slot
 	uint32_t* slice_off;     // [max_slices] word offset of each slice record
 	uint8_t* slice_flags;    // [max_slices] bit0 currentlyCorrect, bit1 falseFromCorrect
 	uint8_t* trace;          // [trace_cap] staging for the traceback moves of the current job
+	uint32_t* ckpt;          // [max_slices + 2] checkpoint records of the reference's DPTable (ramp bookkeeping, wide variants)
+	uint32_t* below_off;     // [max_slices + 1] record standing for slice s when the traceback crosses from slice s + 1
 };
 
 GA_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
@@ -365,16 +367,17 @@ template <int MAXN> GA_FN int processing_order(const GaDevGraph& g, WaveState<MA
 // ---- slice record layout inside the slot arena ---------------------------------------------------------
 struct SliceRec
 {
-	uint32_t* hdr;       // nNodes, nCols, minScore, minSlot, minOffset, reserved
+	uint32_t* hdr;       // kSliceHdrWords
 	uint32_t* nodes;     // [nNodes]
 	uint32_t* colBase;   // [nNodes]
+	int32_t* nodeMin;    // [nNodes] the node minimum the next slice's band selection reads (NodeSlice MapItem<2>)
 	uint64_t* vp;        // [nCols]
 	uint64_t* vn;        // [nCols]
 	int32_t* before;     // [nCols]
 };
 GA_FN uint64_t slice_words(uint32_t nNodes, uint32_t nCols)
 {
-	uint64_t w = kSliceHdrWords + 2ull * nNodes;
+	uint64_t w = kSliceHdrWords + 3ull * nNodes;
 	w += w & 1;                               // 8-byte alignment for the 64-bit planes
 	return w + 5ull * nCols + (nCols & 1);
 }
@@ -384,7 +387,8 @@ GA_FN SliceRec slice_at(uint32_t* arena, uint64_t off, uint32_t nNodes, uint32_t
 	r.hdr = arena + off;
 	r.nodes = r.hdr + kSliceHdrWords;
 	r.colBase = r.nodes + nNodes;
-	uint64_t w = kSliceHdrWords + 2ull * nNodes;
+	r.nodeMin = (int32_t*)(r.colBase + nNodes);
+	uint64_t w = kSliceHdrWords + 3ull * nNodes;
 	w += w & 1;
 	r.vp = (uint64_t*)(arena + off + w);
 	r.vn = r.vp + nCols;
@@ -1196,9 +1200,16 @@ GA_FN int stored_value(const SliceRec& r, uint32_t nNodes, uint32_t node, uint32
 }
 
 // ---- the whole job --------------------------------------------------------------------------------------------
-template <int MAXN>
+// Slice records carry everything needed to continue from them: the narrow variant only ever continues from
+// the slice it has just finished; the wide variants also go back to an earlier one (the ramp redo of
+// getSqrtSlices, GraphAligner.h:2648-2719) and re-run windows from checkpoints (getSlicesFromTable, :2858-2943)
+// when a redo has left the reference's checkpoint list inconsistent with the slices it finally kept.
+constexpr uint32_t kSeedRecord = 0xffffffffu;      // "record" of the initial slice (the seed node at score 0, j = -64)
+
+template <int MAXN, bool GENERAL>
 GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, uint32_t jobIndex)
 {
+	constexpr bool kWide = GENERAL;             // cycles and ramp redos: compiled into the general variants only
 	const GaDevGraph& g = L.graph;
 	const GaJob job = L.jobs[jobIndex];
 	const GaHmmTables& hmm = *L.hmm;
@@ -1213,12 +1224,14 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	const uint32_t numSlices = job.n_rows / W;
 	int status = GA_OK;
 
-	// ---- initial slice: the whole seed node at score 0 (GraphAligner.h:2945-2960) ----
-	int pn = 1;
-	uint32_t seedLen = g_len(g, job.seed_node);
-	if (seedLen > L.cap_cols) status = GA_CAP_COLS;
-	if (status == GA_OK)
-	{
+	// ---- the state a slice is computed from: previous band tables in LDS, packed end scores in end_prev ----
+	int pn = 0;
+	int prevMin = 0;
+	double logCorrect = hmm.init_correct, logWrong = hmm.init_wrong;
+	const uint32_t seedLen = g_len(g, job.seed_node);
+	auto loadSeedState = [&]() {
+		// initial slice: the whole seed node at score 0 (GraphAligner.h:2945-2960)
+		wave_sync();
 		if (GA_LANE0)
 		{
 			ws.pn_node[0] = job.seed_node; ws.pn_min[0] = 0; ws.pn_lastEnd[0] = 0; ws.pn_lastEnd2[0] = 0; ws.pn_colBase[0] = 0;
@@ -1226,48 +1239,89 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			ws.pn_outDeg[0] = 255;          // the seed node's out-list is read from HBM once
 		}
 		for (uint32_t c = 0; c < seedLen; c += LANES) store_lanes(slot.end_prev + c, (int)(seedLen - c), VI(0));
-	}
-	wave_sync();
+		pn = 1; prevMin = 0; logCorrect = hmm.init_correct; logWrong = hmm.init_wrong;
+		wave_sync();
+	};
+	auto loadRecordState = [&](uint32_t off) {
+		// continue from a stored slice: what the reference keeps of it is its frozen end scores (NodeSlice.h:353-376)
+		wave_sync();
+		const uint32_t nN = slot.arena[off], nC = slot.arena[off + 1];
+		const SliceRec r = slice_at(slot.arena, off, nN, nC);
+		for (uint32_t q = 0; q < nN; q++)
+		{
+			const uint32_t base = r.colBase[q];
+			const uint32_t next = q + 1 < nN ? r.colBase[q + 1] : nC;
+			const uint32_t idx = next - 1;
+			const uint64_t vp = r.vp[idx], vn = r.vn[idx];
+			const int e = r.before[idx] + __builtin_popcountll(vp) - __builtin_popcountll(vn);
+			if (GA_LANE0)
+			{
+				ws.pn_node[q] = r.nodes[q]; ws.pn_colBase[q] = base; ws.pn_len[q] = next - base; ws.pn_min[q] = r.nodeMin[q];
+				ws.pn_lastEnd[q] = e; ws.pn_lastEnd2[q] = e - (int)(vp >> 63) + (int)(vn >> 63);
+				ws.pn_outDeg[q] = 255;      // out-lists come from HBM
+			}
+		}
+		for (uint32_t c = 0; c < nC; c += LANES)
+		{
+			const int k = (int)(nC - c);
+			const VU vpV = load_lanes_u64(r.vp + c, k), vnV = load_lanes_u64(r.vn + c, k);
+			const VI endV = load_lanes(r.before + c, k, 0) + vpopc(vpV) - vpopc(vnV);
+			store_lanes(slot.end_prev + c, k, (endV << 2) | vpopc(vpV & VU(1ull << 63)) | (vpopc(vnV & VU(1ull << 63)) << 1));
+		}
+		pn = (int)nN; prevMin = (int)r.hdr[2];
+		union { double d; uint32_t w[2]; } a, b;
+		a.w[0] = r.hdr[6]; a.w[1] = r.hdr[7]; b.w[0] = r.hdr[8]; b.w[1] = r.hdr[9];
+		logCorrect = a.d; logWrong = b.d;
+		wave_sync();
+	};
+
+	if (seedLen > L.cap_cols) status = GA_CAP_COLS;
+	if (status == GA_OK) loadSeedState();
 	VI rowNext = load_lanes(rows, W, 0);
-	int rowAboveCode = 0;
-	int prevMin = 0;
-	double logCorrect = hmm.init_correct, logWrong = hmm.init_wrong;
+	uint32_t rowNextSlice = 0;
+	int rowAboveKept = 0;                      // code of the last row of slice rowAboveFor - 1
+	uint32_t rowAboveFor = 0;
 	uint64_t arenaTop = 0;
 	uint32_t nPushed = 0;          // bandwidthPerSlice.size()
 	uint32_t nRun = 0;
 	const bool rampPossible = L.ramp_bw > L.initial_bw;
 
-	for (uint32_t slice = 0; slice < numSlices && status == GA_OK; slice++)
-	{
-		// slice 0 always runs at the ramp width because rampUntil(0) >= slice(0) (:2603,2612)
-		const int bandwidth = slice == 0 ? L.ramp_bw : L.initial_bw;
-		int cn = 0;
+	// ---- one slice from the loaded state: band, order, fill; the record is written at arenaTop (not yet claimed) ----
+	int cn = 0, sliceMin = 0;
+	uint64_t need = 0;
+	auto runSlice = [&](uint32_t slice, int bandwidth) -> int {
 		uint32_t totalCols = 0;
+		cn = 0;
 		GA_LAP(0);
-		status = project_band(g, ws, pn, prevMin, bandwidth, cn, totalCols);
+		int st = project_band(g, ws, pn, prevMin, bandwidth, cn, totalCols);
 		GA_LAP(1);
-		if (status != GA_OK) break;
-		if (totalCols > L.cap_cols) { status = GA_CAP_COLS; break; }
+		if (st != GA_OK) return st;
+		if (totalCols > L.cap_cols) return GA_CAP_COLS;
 		wave_order();
 		load_topology(g, ws, cn);
 		wave_order();
-		// this slice's row codes arrived during the previous slice; request the next slice's now
+		// this slice's row codes normally arrived during the previous slice; request the next slice's now
+		if (rowNextSlice != slice) rowNext = load_lanes(rows + (uint64_t)slice * W, W, 0);
 		const VI rowCode = rowNext;
-		if (slice + 1 < numSlices) rowNext = load_lanes(rows + (slice + 1) * W, W, 0);
+		const int rowAboveCode = rowAboveFor == slice ? rowAboveKept : (slice > 0 ? (int)rows[(uint64_t)slice * W - 1] : 0);
+		rowAboveKept = read_lane(rowCode, W - 1);
+		rowAboveFor = slice + 1;
+		if (slice + 1 < numSlices) { rowNext = load_lanes(rows + (uint64_t)(slice + 1) * W, W, 0); rowNextSlice = slice + 1; }
 		GA_LAP(2);
-		status = processing_order(g, ws, cn);
+		st = processing_order(g, ws, cn);
 		int nComps = 0;
 		bool cyclicBand = false;
-		if constexpr (MAXN > 32)
+		if constexpr (kWide)
 		{
 			// a band with a cycle is filled by the confirmation-tracking path (wide kernel variants only; the
 			// narrow variant reports GA_UNSUPPORTED_CYCLE and the job is rerun by a wide one)
-			if (status == GA_UNSUPPORTED_CYCLE) { wave_order(); status = scc_order(g, ws, cn, nComps); cyclicBand = true; }
+			if (st == GA_UNSUPPORTED_CYCLE) { wave_order(); st = scc_order(g, ws, cn, nComps); cyclicBand = true; }
 		}
 		GA_LAP(3);
-		if (status != GA_OK) break;
-		uint64_t need = slice_words((uint32_t)cn, totalCols);
-		if (arenaTop + need > L.arena_words) { status = GA_CAP_ARENA; break; }
+		if (st != GA_OK) return st;
+		need = slice_words((uint32_t)cn, totalCols);
+		if (arenaTop + need > L.arena_words) return GA_CAP_ARENA;
+		if (arenaTop + need >= 0xffffffffull) return GA_CAP_ARENA;
 		SliceRec rec = slice_at(slot.arena, arenaTop, (uint32_t)cn, totalCols);
 		for (int c = 0; c < cn; c += LANES)
 		{
@@ -1275,42 +1329,30 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			store_lanes(rec.colBase + c, cn - c, load_lanes(ws.cn_colBase + c, cn - c, 0));
 		}
 		wave_order();
-		int sliceMin, minSlot;
+		int minSlot;
 		uint32_t minOffset;
 		GA_LAP(0);
-		if constexpr (MAXN > 32)
+		if constexpr (kWide)
 		{
-			if (cyclicBand) status = fill_slice_general(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, prevMin, pn, cn, nComps, sliceMin, minSlot, minOffset);
-			else status = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
+			if (cyclicBand) st = fill_slice_general(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, prevMin, pn, cn, nComps, sliceMin, minSlot, minOffset);
+			else st = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
 		}
-		else status = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
-		rowAboveCode = read_lane(rowCode, W - 1);
+		else st = fill_slice(g, ws, slot, rec, rowCode, rowAboveCode, job.n_rows, slice * W, pn, cn, sliceMin, minSlot, minOffset);
 		GA_LAP(4);
-		if (status != GA_OK) break;
-		if (sliceMin < prevMin) { status = GA_ASSERTION; break; }                 // :2469
+		if (st != GA_OK) return st;
+		if (sliceMin < prevMin) return GA_ASSERTION;                              // :2469
+		wave_order();
+		for (int c = 0; c < cn; c += LANES) store_lanes(rec.nodeMin + c, cn - c, load_lanes(ws.cn_min + c, cn - c, 0));
 		if (GA_LANE0)
 		{
 			rec.hdr[0] = (uint32_t)cn; rec.hdr[1] = totalCols; rec.hdr[2] = (uint32_t)sliceMin; rec.hdr[3] = (uint32_t)minSlot; rec.hdr[4] = minOffset; rec.hdr[5] = 0;
-			slot.slice_off[slice] = (uint32_t)arenaTop;
 		}
-		nRun++;
 		out.n_columns += totalCols;
 		out.max_band_nodes = out.max_band_nodes > (uint32_t)cn ? out.max_band_nodes : (uint32_t)cn;
-		// ---- HMM step (AlignmentCorrectnessEstimation.cpp:71-89): additions and comparisons only ----
-		int mism = sliceMin - prevMin;
-		if (mism > 64) { status = GA_ASSERTION; break; }
-		double cc = logCorrect + hmm.c2c, fc = logWrong + hmm.f2c, cf = logCorrect + hmm.c2f, ff = logWrong + hmm.f2f;
-		bool correctFromCorrect = cc >= fc;
-		bool falseFromCorrect = cf >= ff;
-		logCorrect = (cc > fc ? cc : fc) + hmm.correct_mult[mism];
-		logWrong = (cf > ff ? cf : ff) + hmm.wrong_mult[mism];
-		bool currentlyCorrect = logCorrect > logWrong;
-		if (!correctFromCorrect) break;                                          // :2640-2647 (this slice is not kept)
-		if (!currentlyCorrect && slice > 0 && rampPossible) { status = GA_UNSUPPORTED_RAMP; break; }   // :2648
-		if (GA_LANE0) slot.slice_flags[slice] = (uint8_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0));
-		nPushed++;
-		arenaTop += need;
-		// ---- current band becomes the previous one ----
+		return GA_OK;
+	};
+	// the slice just computed becomes the state
+	auto adoptSlice = [&]() {
 		wave_order();
 		for (int c = 0; c < cn; c += LANES)
 		{
@@ -1328,6 +1370,98 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		prevMin = sliceMin;
 		uint32_t* t = slot.end_prev; slot.end_prev = slot.end_cur; slot.end_cur = t;
 		wave_sync();
+	};
+
+	// ---- first pass (getSqrtSlices, GraphAligner.h:2571-2856) ----
+	// checkpoint bookkeeping of the reference, needed only to reproduce what a ramp redo does to it
+	uint32_t sampling = 0;
+	while ((sampling + 1) * (sampling + 1) <= numSlices) sampling++;            // (int)sqrt(len / 64) (:2962-2967)
+	uint32_t lastRec = kSeedRecord, rampRec = kSeedRecord, storeRec = kSeedRecord;
+	uint32_t storeMem = 28, rampUntil = 0, rampRedoIndex = 0xffffffffu, nCkpt = 0;
+	bool redone = false;
+	auto recSlice = [&](uint32_t recOff) -> uint32_t { return recOff == kSeedRecord ? 0xffffffffu : slot.arena[recOff + 10]; };   // slice index of a record (-1 for the seed)
+	for (uint32_t slice = 0; slice < numSlices && status == GA_OK; slice++)
+	{
+		// slice 0 always runs at the ramp width because rampUntil(0) >= slice(0) (:2603,2612)
+		const bool useRamp = rampUntil >= slice;
+		const int bandwidth = useRamp ? L.ramp_bw : L.initial_bw;
+		status = runSlice(slice, bandwidth);
+		if (status != GA_OK) break;
+		const uint32_t thisRec = (uint32_t)arenaTop;
+		nRun++;
+		// ---- HMM step (AlignmentCorrectnessEstimation.cpp:71-89): additions and comparisons only ----
+		int mism = sliceMin - prevMin;
+		if (mism > 64) { status = GA_ASSERTION; break; }
+		double cc = logCorrect + hmm.c2c, fc = logWrong + hmm.f2c, cf = logCorrect + hmm.c2f, ff = logWrong + hmm.f2f;
+		bool correctFromCorrect = cc >= fc;
+		bool falseFromCorrect = cf >= ff;
+		const double newCorrect = (cc > fc ? cc : fc) + hmm.correct_mult[mism];
+		const double newWrong = (cf > ff ? cf : ff) + hmm.wrong_mult[mism];
+		bool currentlyCorrect = newCorrect > newWrong;
+		if constexpr (kWide)
+		{
+			if (rampPossible && ((slice > 0 && rampUntil == slice - 1) || (rampUntil < slice && currentlyCorrect && falseFromCorrect)))
+			{
+				rampRec = lastRec;                                               // :2630-2634 (the band is always below the cutoff here)
+				rampRedoIndex = slice - 1;
+			}
+		}
+		if (!correctFromCorrect) break;                                          // :2640-2647 (this slice is not kept)
+		if (!currentlyCorrect && rampUntil < slice && rampPossible)
+		{
+			if constexpr (!kWide) { status = GA_UNSUPPORTED_RAMP; break; }       // rerun by a wide variant
+			else
+			{
+				// ---- go back to the remembered slice and come forward again at the ramp width (:2648-2719) ----
+				rampUntil = slice;
+				const uint32_t back = rampRedoIndex;
+				rampRedoIndex = slice;
+				const uint32_t backRec = rampRec;
+				rampRec = lastRec;
+				lastRec = backRec;
+				if (backRec == kSeedRecord) loadSeedState(); else loadRecordState(backRec);
+				nPushed = back + 1;                                              // bandwidthPerSlice / correctness shrink to back + 1 entries
+				while (nCkpt > 1 && slot.ckpt[nCkpt - 1] != kSeedRecord && recSlice(slot.ckpt[nCkpt - 1]) > back) nCkpt--;
+				redone = true;
+				slice = back;                                                    // the loop increment makes it back + 1
+				continue;
+			}
+		}
+		if (GA_LANE0)
+		{
+			uint32_t* hdr = slot.arena + arenaTop;
+			union { double d; uint32_t w[2]; } a, b;
+			a.d = newCorrect; b.d = newWrong;
+			hdr[5] = (uint32_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0) | (useRamp ? 4 : 0));
+			hdr[6] = a.w[0]; hdr[7] = a.w[1]; hdr[8] = b.w[0]; hdr[9] = b.w[1]; hdr[10] = slice;
+			slot.slice_off[slice] = thisRec;
+			slot.slice_flags[slice] = (uint8_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0) | (useRamp ? 4 : 0));
+		}
+		if (nPushed != slice) { status = GA_ASSERTION; break; }                  // :2768
+		nPushed++;
+		const uint32_t thisMem = slot.arena[arenaTop + 1] * 4 + (uint32_t)cn * 28;   // estimatedMemory (:136-139)
+		arenaTop += need;
+		logCorrect = newCorrect; logWrong = newWrong;
+		if constexpr (kWide)
+		{
+			if (rampPossible)
+			{
+				// checkpoint = cheapest slice of each sqrt window (:2772-2786)
+				if (slice % sampling == 0)
+				{
+					if (nCkpt == 0 || recSlice(storeRec) != recSlice(slot.ckpt[nCkpt - 1]))
+					{
+						if (GA_LANE0) slot.ckpt[nCkpt] = storeRec;
+						nCkpt++;
+						storeRec = thisRec; storeMem = thisMem;
+					}
+				}
+				if (thisMem < storeMem) { storeRec = thisRec; storeMem = thisMem; }
+				wave_order();
+			}
+		}
+		lastRec = thisRec;
+		adoptSlice();
 	}
 	out.n_run = nRun;
 	GA_LAP(0);
@@ -1347,6 +1481,69 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	}
 	out.n_valid = status == GA_OK ? kept : 0;
 
+	// ---- after a ramp redo the slices the traceback sees are those the reference would recompute from its
+	// checkpoints (getSlicesFromTable :2858-2943); a checkpoint taken before the redo can disagree with the slices kept ----
+	const uint32_t* inTab = slot.slice_off;       // record traced through, per slice
+	const uint32_t* belowTab = slot.slice_off;    // record standing for the slice above a slice boundary
+	uint32_t startRec = kept > 0 ? slot.slice_off[kept - 1] : 0;
+	if constexpr (kWide)
+	{
+		if (status == GA_OK && redone && kept > 0 && numSlices >= 4)
+		{
+			wave_sync();
+			const auto firstPassColumns = out.n_columns;                          // the column-update count is the first pass's (cellsProcessed)
+			const auto firstPassNodes = out.max_band_nodes;
+			if (nCkpt == 0) status = GA_ASSERTION;                                // :2834
+			// trimmed checkpoints (:2566-2568)
+			while (status == GA_OK && nCkpt > 1 && slot.ckpt[nCkpt - 1] != kSeedRecord && recSlice(slot.ckpt[nCkpt - 1]) >= kept) nCkpt--;
+			for (uint32_t i = 1; i < nCkpt && status == GA_OK; i++)
+			{
+				const uint32_t a = slot.ckpt[i - 1], b = slot.ckpt[i];
+				if (i >= 2 && !(recSlice(b) > recSlice(a))) status = GA_ASSERTION;                 // :2835-2838
+				const int ma = a == kSeedRecord ? 0 : (int)slot.arena[a + 2], mb = b == kSeedRecord ? 0 : (int)slot.arena[b + 2];
+				if (mb < ma) status = GA_ASSERTION;                                                // :2839-2842
+			}
+			for (uint32_t sIdx = 0; sIdx < kept; sIdx++) if (GA_LANE0) slot.below_off[sIdx] = slot.slice_off[sIdx];
+			wave_sync();
+			for (uint32_t i = nCkpt; i-- > 0 && status == GA_OK;)
+			{
+				const uint32_t ck = slot.ckpt[i];
+				const uint32_t ckSlice = recSlice(ck);                               // 0xffffffff for the seed
+				const uint32_t firstSlice = ckSlice + 1;                             // wraps to 0 for the seed
+				const uint32_t endSlice = i + 1 == nCkpt ? kept : recSlice(slot.ckpt[i + 1]) + 1;
+				if (ck != kSeedRecord && GA_LANE0) slot.below_off[ckSlice] = ck;
+				if (firstSlice == kept)
+				{
+					if (i + 1 != nCkpt) status = GA_ASSERTION;                       // :911
+					continue;
+				}
+				if (!(endSlice > firstSlice) || endSlice > kept) { status = GA_ASSERTION; break; }   // :2862-2866
+				const bool consistent = ck == kSeedRecord || ck == slot.slice_off[ckSlice];
+				if (consistent) continue;                                            // the recompute would reproduce the kept slices
+				loadRecordState(ck);
+				for (uint32_t sl = firstSlice; sl < endSlice && status == GA_OK; sl++)
+				{
+					const int bandwidth = (slot.slice_flags[sl] & 4) ? L.ramp_bw : L.initial_bw;
+					status = runSlice(sl, bandwidth);
+					if (status != GA_OK) break;
+					if (GA_LANE0) { slot.arena[arenaTop + 10] = sl; slot.slice_off[sl] = (uint32_t)arenaTop; if (sl + 1 < endSlice || i + 1 == nCkpt) slot.below_off[sl] = (uint32_t)arenaTop; }
+					arenaTop += need;
+					adoptSlice();
+				}
+			}
+			wave_sync();
+			if (status == GA_OK)
+			{
+				// the trace starts at the last checkpoint when that is the last kept slice itself (:908-916), else at the last slice of the last window
+				const uint32_t lastCk = slot.ckpt[nCkpt - 1];
+				startRec = (lastCk != kSeedRecord && recSlice(lastCk) + 1 == kept) ? lastCk : slot.slice_off[kept - 1];
+			}
+			belowTab = slot.below_off;
+			out.n_columns = firstPassColumns;
+			out.max_band_nodes = firstPassNodes;
+		}
+	}
+
 	// ---- traceback (getTraceFromTable :894-957 with pickBacktracePredecessor :493-591) ----
 	if (status == GA_OK && kept > 0)
 	{
@@ -1357,12 +1554,13 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		uint8_t* tr = slot.trace;
 		const int big = (int)job.n_rows;                                         // getValueOrMax default = sequence.size()
 		uint32_t sIdx = kept - 1;
-		uint32_t off = slot.slice_off[sIdx];
+		uint32_t off = inTab[sIdx];
 		uint32_t nN = slot.arena[off], nC = slot.arena[off + 1];
 		SliceRec cur = slice_at(slot.arena, off, nN, nC);
-		out.score = (int32_t)cur.hdr[2];
-		uint32_t node = cur.nodes[cur.hdr[3]];
-		uint32_t offset = cur.hdr[4];
+		const SliceRec from = slice_at(slot.arena, startRec, slot.arena[startRec], slot.arena[startRec + 1]);   // = cur unless a ramp redo left a stale checkpoint
+		out.score = (int32_t)from.hdr[2];
+		uint32_t node = from.nodes[from.hdr[3]];
+		uint32_t offset = from.hdr[4];
 		uint32_t row = sIdx * W + (W - 1);
 		uint32_t len = 0;
 		out.start_node = node; out.start_offset = offset; out.start_row = row;
@@ -1370,7 +1568,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		uint32_t pN = 0;
 		auto loadPrev = [&]() {
 			if (sIdx == 0) return;
-			uint32_t o = slot.slice_off[sIdx - 1];
+			uint32_t o = belowTab[sIdx - 1];
 			pN = slot.arena[o];
 			prv = slice_at(slot.arena, o, pN, slot.arena[o + 1]);
 		};
@@ -1537,7 +1735,15 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			{
 				// stepped into the slice above
 				sIdx--;
-				cur = prv; nN = pN;
+				if (belowTab[sIdx] == inTab[sIdx]) { cur = prv; nN = pN; }
+				else
+				{
+					// the slice is traced through in another version than the one the boundary step looked at
+					const uint32_t o = inTab[sIdx];
+					nN = slot.arena[o];
+					cur = slice_at(slot.arena, o, nN, slot.arena[o + 1]);
+					pw.valid = false;
+				}
 				loadPrev();
 			}
 		}

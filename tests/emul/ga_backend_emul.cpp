@@ -35,12 +35,13 @@ struct EmulBatch : GaBackendBatch
 	uint64_t poolTop = 0;
 	uint64_t retried = 0;
 
-	template <int MAXN> void runOne(uint32_t job, uint32_t capCols, uint64_t arenaWords, uint32_t traceCap)
+	template <int MAXN, bool GENERAL> void runOne(uint32_t job, uint32_t capCols, uint64_t arenaWords, uint32_t traceCap)
 	{
 		std::vector<uint32_t> endA(capCols), endB(capCols), arena(arenaWords), sliceOff(cfg.max_slices + 1);
 		std::vector<uint8_t> flags(cfg.max_slices + 1);
 		std::vector<uint8_t> staging(traceCap + 64);
-		gak::Slot slot{endA.data(), endB.data(), arena.data(), sliceOff.data(), flags.data(), staging.data()};
+		std::vector<uint32_t> ckpt(cfg.max_slices + 2), below(cfg.max_slices + 1);
+		gak::Slot slot{endA.data(), endB.data(), arena.data(), sliceOff.data(), flags.data(), staging.data(), ckpt.data(), below.data()};
 		GaLaunch L;
 		memset(&L, 0, sizeof(L));
 		L.graph = g->dev; L.hmm = &g->hmm; L.rows = rows.data(); L.jobs = jobs.data(); L.outs = outs.data();
@@ -48,7 +49,7 @@ struct EmulBatch : GaBackendBatch
 		L.n_jobs = (uint32_t)jobs.size(); L.trace_cap = traceCap; L.cap_cols = capCols; L.max_slices = cfg.max_slices;
 		L.arena_words = arenaWords; L.initial_bw = cfg.initial_bw; L.ramp_bw = cfg.ramp_bw;
 		auto ws = std::make_unique<gak::WaveState<MAXN>>();
-		gak::run_job<MAXN>(L, *ws, slot, job);
+		gak::run_job<MAXN, GENERAL>(L, *ws, slot, job);
 	}
 
 	int run() override
@@ -62,14 +63,15 @@ struct EmulBatch : GaBackendBatch
 		for (uint32_t j = 0; j < jobs.size(); j++)
 		{
 			uint32_t slices = jobs[j].n_rows / 64;
-			// deliberately small first-try capacities so the retry path is exercised too
-			runOne<32>(j, 2048, 64 + (uint64_t)slices * (6 + 2 * 40 + 5 * 700), jobs[j].n_rows * 2 + 512);
-			int s = outs[j].status;
-			if (s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP || s == GA_UNSUPPORTED_CYCLE)
-			{
-				retried++;
-				runOne<256>(j, 200000, 64 + (uint64_t)slices * (6 + 2 * 256 + 5 * 20000), jobs[j].n_rows * 8 + 4096);
-			}
+			// deliberately small first-try capacities so the retry ladder is exercised too
+			runOne<32, false>(j, 2048, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 40 + 5 * 700), jobs[j].n_rows * 2 + 512);
+			auto capacity = [](int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; };
+			auto general = [](int s) { return s == GA_UNSUPPORTED_CYCLE || s == GA_UNSUPPORTED_RAMP; };
+			if (capacity(outs[j].status) || general(outs[j].status)) retried++;
+			if (general(outs[j].status))
+				runOne<64, true>(j, 4096, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 64 + 5 * 1500) * 2, jobs[j].n_rows * 3 + 1024);
+			if (capacity(outs[j].status) || general(outs[j].status))
+				runOne<256, true>(j, 200000, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 256 + 5 * 20000) * 3, jobs[j].n_rows * 8 + 4096);
 		}
 		return 0;
 	}

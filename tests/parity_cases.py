@@ -56,6 +56,48 @@ def case_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span, lib_path=
     assert n_cyclic_jobs > 0
 
 
+RAMP_CASES = [(8, 5, 35, 0.03), (16, 10, 40, 0.06), (32, 3, 20, 0.03), (64, 15, 80, 0.1)]
+
+
+def damaged_reads(reads, rng):
+    """cut, insert or replace a stretch of 8..180 bases a few times per read: a narrow band loses
+    the path there and the reference goes back and widens it (-B, GraphAligner.h:2648-2719)"""
+    out = []
+    for r in reads:
+        r = list(r)
+        for _ in range(int(rng.integers(1, 4))):
+            if len(r) < 500:
+                break
+            p = int(rng.integers(200, len(r) - 200))
+            kind = int(rng.integers(3))
+            n = int(rng.integers(8, 60))
+            junk = lambda k: ["ACGT"[int(x)] for x in rng.integers(0, 4, k)]
+            if kind == 0:
+                del r[p:p + n]
+            elif kind == 1:
+                r[p:p] = junk(n)
+            else:
+                r[p:p + n * 3] = junk(n * 3)
+        out.append("".join(r))
+    return out
+
+
+def case_ramp_redo(node_len, bw, ramp, err, lib_path=None):
+    """-B ramp bandwidth: when the HMM turns "wrong" the reference returns to a remembered slice
+    and recomputes with the wide band; its checkpoint list is not rewound with it, so the slices
+    its traceback recomputes can differ from the ones it kept (and sometimes assert) -- all of
+    which has to come out the same."""
+    rng = np.random.default_rng(node_len * 7 + bw)
+    g = synth.SynthGraph(synth.random_genome(30000, 900 + node_len), node_len=node_len, snp_every=60, indel_every=400, seed=node_len)
+    n_ok = 0
+    for length, mid in [(1500, False), (3000, True), (6000, False)]:
+        reads, seeds = synth.simulate_reads(g, 8, length, sub=err, ins=err, dele=err, seed=length + bw, mid_seed=mid)
+        reads = damaged_reads(reads, rng)
+        devs, oras = pc.check_parity(g.nodes, g.edges, reads, seeds, bw, ramp=ramp, lib_path=lib_path, ctx="ramp nl%d bw%d/%d len%d" % (node_len, bw, ramp, length))
+        n_ok += sum(1 for d in devs if d["status"] == 0 and not d["failed"])
+    assert n_ok >= 12, n_ok
+
+
 def case_short_and_edge_reads(lib_path=None):
     """directions shorter than 193 bp hit assert(samplingFrequency > 1) in the reference
     (GraphAligner.h:906); seeds at the last base align backwards only (:3006)"""

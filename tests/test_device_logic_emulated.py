@@ -27,6 +27,11 @@ def test_cyclic_graphs(lib, node_len, bw, back_edges, self_loops, max_span):
     cases.case_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span, lib)
 
 
+@pytest.mark.parametrize("node_len,bw,ramp,err", cases.RAMP_CASES)
+def test_ramp_redo(lib, node_len, bw, ramp, err):
+    cases.case_ramp_redo(node_len, bw, ramp, err, lib)
+
+
 def test_short_and_edge_reads(lib):
     cases.case_short_and_edge_reads(lib)
 

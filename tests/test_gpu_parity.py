@@ -29,6 +29,11 @@ def test_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span):
     cases.case_cyclic_graphs(node_len, bw, back_edges, self_loops, max_span)
 
 
+@pytest.mark.parametrize("node_len,bw,ramp,err", cases.RAMP_CASES)
+def test_ramp_redo(node_len, bw, ramp, err):
+    cases.case_ramp_redo(node_len, bw, ramp, err)
+
+
 def test_short_and_edge_reads():
     cases.case_short_and_edge_reads()
 
