@@ -59,7 +59,7 @@ def _check_case(case, results):
 def test_oracle_reproduces_golden_vectors():
     for case in _load("oracle_vectors.json")["cases"]:
         og = ob.OracleGraph([tuple(x) for x in case["nodes"]], [tuple(x) for x in case["edges"]])
-        res = [og.align(r, [tuple(s)], case["bandwidth"]) for r, s in zip(case["reads"], case["seeds"])]
+        res = [og.align(r, [tuple(s)], case["bandwidth"], case.get("ramp", 0)) for r, s in zip(case["reads"], case["seeds"])]
         _check_case(case, res)
 
 
@@ -67,7 +67,7 @@ def run_device_on_golden(lib_path):
     from graphaligner_amd import binding
     for case in _load("oracle_vectors.json")["cases"]:
         g = binding.Graph([tuple(x) for x in case["nodes"]], [tuple(x) for x in case["edges"]], lib_path=lib_path)
-        res = g.align(case["reads"], [tuple(s) for s in case["seeds"]], case["bandwidth"], flags=binding.GA_F_TRACE)
+        res = g.align(case["reads"], [tuple(s) for s in case["seeds"]], case["bandwidth"], case.get("ramp", 0), flags=binding.GA_F_TRACE)
         _check_case(case, res)
     for name, seedf in (("ref_gwws_fail_ex1.json", None), ("ref_smallexample.json", None)):
         d = _load(name)

@@ -141,19 +141,32 @@ def main():
     specs = [("linear64", dict(node_len=64), 35, False), ("snp32", dict(node_len=32, snp_every=60), 35, True),
              ("indel16", dict(node_len=16, snp_every=80, indel_every=200), 35, False), ("sv32", dict(node_len=32, snp_every=100, indel_every=500, sv_every=2500), 35, True),
              ("tiny5", dict(node_len=5, snp_every=30), 10, False), ("wideband", dict(node_len=32, snp_every=50, indel_every=300), 80, True)]
+    import parity_cases
+    built = []
     for k, (name, gargs, bw, mid) in enumerate(specs):
         g = synth.SynthGraph(synth.random_genome(12000, 900 + k), seed=k, **gargs)
         reads, seeds = synth.simulate_reads(g, 4, 900, seed=100 + k, mid_seed=mid)
         reads[1] = reads[1][:150]                                   # too short: assert(samplingFrequency > 1)
+        built.append((name, g, reads, seeds, bw, 0))
+    # bands with cycles (tandem-repeat back edges, self loops), reads that go round them
+    g = synth.cyclic_graph(5000, node_len=12, seed=3, back_edges=8, self_loops=2, max_span=4)
+    reads, seeds = synth.walk_reads(g, 4, 900, seed=31, mid_seed=True, first_nodes=len(g.nodes) // 3)
+    built.append(("cyclic12", g, reads, seeds, 35, 0))
+    # -B ramp redo: damaged reads, narrow initial band
+    g = synth.SynthGraph(synth.random_genome(30000, 916), node_len=16, snp_every=60, indel_every=400, seed=16)
+    reads, seeds = synth.simulate_reads(g, 6, 3000, sub=0.06, ins=0.06, dele=0.06, seed=3010, mid_seed=True)
+    reads = parity_cases.damaged_reads(reads, np.random.default_rng(122))
+    built.append(("ramp16", g, reads, seeds, 10, 40))
+    for name, g, reads, seeds, bw, ramp in built:
         og = ob.OracleGraph(g.nodes, g.edges)
         exp = []
         for r, s in zip(reads, seeds):
-            o = og.align(r, [s], bw)
+            o = og.align(r, [s], bw, ramp)
             exp.append(dict(status=o["status"], failed=o["failed"], score=o["score"], query_position=o["query_position"],
                             alignment_start=o["alignment_start"], alignment_end=o["alignment_end"], columns=o["columns"],
                             mappings=[list(m) for m in o["mappings"]], n_trace=int(o["trace"].shape[0]),
                             trace_checksum=int(np.asarray(o["trace"], dtype=np.int64).sum() % (1 << 61))))
-        cases.append(dict(name=name, bandwidth=bw, nodes=[[i, s] for i, s in g.nodes], edges=[list(map(int, e)) for e in g.edges],
+        cases.append(dict(name=name, bandwidth=bw, ramp=ramp, nodes=[[i, s] for i, s in g.nodes], edges=[list(map(int, e)) for e in g.edges],
                           reads=reads, seeds=[list(map(int, s)) for s in seeds], expected=exp))
     json.dump(dict(provenance="expected values produced by this repository's CPU oracle (oracle/ga_oracle.cpp); parity unpinned against the reference",
                    generator="tools/make_golden.py", cases=cases), open(os.path.join(OUT, "oracle_vectors.json"), "w"))
