@@ -15,6 +15,8 @@ PRODUCT_SO = os.path.join(HERE, "libgraphaligner_amd.so")
 STATUS = {0: "OK", 1: "ASSERTION", 2: "UNSUPPORTED_BAND", 3: "BAD_SEED", 10: "CAPACITY", 20: "UNSUPPORTED_CYCLE", 21: "UNSUPPORTED_RAMP",
           100: "E_INVALID", 101: "E_NO_DEVICE", 102: "E_DEVICE", 103: "E_NOT_FINALIZED"}
 GA_F_TRACE = 1
+GA_S_OK = 0
+GA_S_ASSERTION = 1
 
 
 class GaRead(C.Structure):
@@ -143,9 +145,9 @@ class Graph:
     def bp(self):
         return self.L.ga_graph_bp(self.h)
 
-    def prepare(self, reads, seeds, bw, ramp=0, flags=0):
+    def prepare(self, reads, seeds, bw, ramp=0, flags=0, names=None):
         """reads: list of str; seeds: list (one entry per read) of lists of (node, pos, reverse) or a single tuple"""
-        return Batch(self, reads, seeds, bw, ramp, flags)
+        return Batch(self, reads, seeds, bw, ramp, flags, names)
 
     def align(self, reads, seeds, bw, ramp=0, flags=0):
         b = self.prepare(reads, seeds, bw, ramp, flags)
@@ -154,14 +156,15 @@ class Graph:
 
 
 class Batch:
-    def __init__(self, graph, reads, seeds, bw, ramp, flags):
+    def __init__(self, graph, reads, seeds, bw, ramp, flags, names=None):
         self.g = graph
         L = self.L = graph.L
         n = len(reads)
         self._keep = [r.encode() if isinstance(r, str) else r for r in reads]
         arr = (GaRead * max(n, 1))()
+        self._names = [(names[i].encode() if names is not None else b"read%d" % i) for i in range(n)]
         for i, r in enumerate(self._keep):
-            arr[i].name = b"read%d" % i
+            arr[i].name = self._names[i]
             arr[i].sequence = r
             arr[i].length = len(r)
         flat = []
@@ -228,6 +231,10 @@ class Batch:
                 self.L.ga_batch_free(self.h)
         except Exception:
             pass
+
+
+def status_string(status, lib_path=None):
+    return load(lib_path).ga_status_string(int(status)).decode()
 
 
 def decode_seed_gam(data, lib_path=None):
