@@ -68,7 +68,9 @@ template <int MAXN> struct WaveState
 	// topology of the band nodes, fetched once per slice with all lanes in parallel
 	uint32_t cn_startLo[MAXN], cn_startHi[MAXN];   // first column of the node in the graph
 	uint8_t cn_inDeg[MAXN], cn_outDeg[MAXN];      // > kNbr: the list lives in HBM only
-	uint32_t cn_inNbr[MAXN * 4], cn_outNbr[MAXN * 4];
+	uint32_t cn_outNbr[MAXN * 4];
+	// where each cached neighbour sits in the current / previous band (-1 = not there), looked up once per slice
+	int16_t cn_inSlotC[MAXN * 4], cn_inSlotP[MAXN * 4], cn_outSlotC[MAXN * 4];
 	uint8_t color[MAXN];
 	int16_t post[MAXN];          // Tarjan emission order
 	int16_t low[MAXN];           // Tarjan low-link / component number (bands with cycles only)
@@ -158,6 +160,51 @@ template <int MAXN> GA_FN void hash_order(WaveState<MAXN>& ws, const uint32_t* k
 	for (int p = head; p >= 0; p = ws.h_next[p]) ws.h_order[k++] = (int16_t)p;
 }
 
+// The same order computed with lanes = elements (n <= 64).  Inserting a sequence of distinct keys into an empty
+// table with B buckets leaves the list grouped by bucket, the groups ordered by the time their bucket was first
+// used (latest first) and each group by insertion time (latest first): a node entering an empty bucket goes to
+// the list head, any other node to the front of its bucket's group.  A rehash re-inserts the current list, in
+// list order, into the grown table, after which insertion continues; so every growth stage is one such
+// grouping of the sequence "current list, then the keys added before the next growth".
+template <int B> GA_FN VI hash_stage_rank(const VI key, int m)
+{
+	const VI lane = lane_iota();
+	const VI b = vmod<B>(key);
+	// f = first position in the sequence whose key shares my bucket
+	VI f = lane;
+	for (int j = m - 1; j >= 0; j--) f = select(b == read_lane(b, j), VI(j), f);
+	// rank = how many elements precede me: later-opened groups, then later members of my own group
+	VI rank = VI(0);
+	for (int j = 0; j < m; j++)
+	{
+		const int fj = read_lane(f, j);
+		rank = rank + select((f < fj) , VI(1), select((f == fj) && (lane < j), VI(1), VI(0)));
+	}
+	return rank;
+}
+template <int MAXN> GA_FN void hash_order_lanes(WaveState<MAXN>& ws, const uint32_t* keys, int n)
+{
+	const VI lane = lane_iota();
+	int done = 0;                                                // elements already in the list (h_order[0..done) = list order)
+	for (int stage = 0; done < n; stage++)
+	{
+		const int upto = stage == 0 ? 13 : stage == 1 ? 29 : stage == 2 ? 59 : 127;     // the table grows when the 14th, 30th, 60th key arrives
+		const int m = n < upto ? n : upto;
+		const VB live = lane < m;
+		const VI elem = select(lane < done, load_lanes(ws.h_order, done, 0), lane);
+		const VI key = select(live, gather(keys, select(live, elem, VI(0))), VI(0));
+		VI rank;
+		if (stage == 0) rank = hash_stage_rank<13>(key, m);
+		else if (stage == 1) rank = hash_stage_rank<29>(key, m);
+		else if (stage == 2) rank = hash_stage_rank<59>(key, m);
+		else rank = hash_stage_rank<127>(key, m);
+		wave_order();
+		scatter(ws.h_order, rank, elem, live);
+		wave_order();
+		done = m;
+	}
+}
+
 // ---- std::priority_queue<.., std::greater<>> over (node, priority), libstdc++ heap algorithms -----
 // (GraphAligner.h:1115; the pop order among equal priorities decides DPSlice::nodes order)
 template <int MAXN> GA_FN void heap_sift_up(WaveState<MAXN>& ws, int hole, int top, uint32_t node, int prio)
@@ -214,7 +261,7 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 	cn = 0;
 	totalCols = 0;
 	int heapSize = 0;
-	hash_order(ws, ws.pn_node, pn);
+	if (pn <= LANES) hash_order_lanes(ws, ws.pn_node, pn); else hash_order(ws, ws.pn_node, pn);
 	auto add = [&](uint32_t node, int prevSlot, uint32_t len) -> bool {
 		if (cn >= MAXN) return false;
 		ws.cn_node[cn] = node;
@@ -273,7 +320,10 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 }
 
 // ---- fetch the band nodes' topology into LDS: lanes = band nodes, one round trip to HBM/L2 ------------
-template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN>& ws, int cn)
+// The neighbours' positions in the current and the previous band are looked up here as well, for all band
+// nodes at once (one pass over the band lists, every lane comparing its own neighbours), so that the
+// per-node code finds them with one LDS read instead of a search.
+template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN>& ws, int pn, int cn)
 {
 	const VI lane = lane_iota();
 	const uint32_t* startWords = (const uint32_t*)g.node_start;
@@ -291,33 +341,67 @@ template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN
 		scatter(ws.cn_startHi, slot, hi, live);
 		scatter(ws.cn_inDeg, slot, vmin(inDeg, VI(255)), live);
 		scatter(ws.cn_outDeg, slot, vmin(outDeg, VI(255)), live);
+		VI inN[kNbr], outN[kNbr], inC[kNbr], inP[kNbr], outC[kNbr];
 		for (int k = 0; k < kNbr; k++)
 		{
 			VB hasIn = live && (VI(k) < inDeg);
 			VB hasOut = live && (VI(k) < outDeg);
-			VI inN = gather(g.in_nbr, select(hasIn, in0 + k, VI(0)));
-			VI outN = gather(g.out_nbr, select(hasOut, out0 + k, VI(0)));
-			scatter(ws.cn_inNbr, (slot << 2) + k, inN, hasIn);
-			scatter(ws.cn_outNbr, (slot << 2) + k, outN, hasOut);
+			inN[k] = select(hasIn, gather(g.in_nbr, select(hasIn, in0 + k, VI(0))), VI(-1));
+			outN[k] = select(hasOut, gather(g.out_nbr, select(hasOut, out0 + k, VI(0))), VI(-1));
+			scatter(ws.cn_outNbr, (slot << 2) + k, outN[k], hasOut);
+			inC[k] = VI(-1); inP[k] = VI(-1); outC[k] = VI(-1);
+		}
+		for (int jb = 0; jb < cn; jb += LANES)
+		{
+			const int m = cn - jb < LANES ? cn - jb : LANES;
+			const VI nodesJ = load_lanes(ws.cn_node + jb, m, -2);
+			for (int j = 0; j < m; j++)
+			{
+				const int nj = read_lane(nodesJ, j);
+				for (int k = 0; k < kNbr; k++)
+				{
+					inC[k] = select(inN[k] == nj, VI(jb + j), inC[k]);
+					outC[k] = select(outN[k] == nj, VI(jb + j), outC[k]);
+				}
+			}
+		}
+		for (int jb = 0; jb < pn; jb += LANES)
+		{
+			const int m = pn - jb < LANES ? pn - jb : LANES;
+			const VI nodesJ = load_lanes(ws.pn_node + jb, m, -2);
+			for (int j = 0; j < m; j++)
+			{
+				const int nj = read_lane(nodesJ, j);
+				for (int k = 0; k < kNbr; k++) inP[k] = select(inN[k] == nj, VI(jb + j), inP[k]);
+			}
+		}
+		for (int k = 0; k < kNbr; k++)
+		{
+			scatter(ws.cn_inSlotC, (slot << 2) + k, inC[k], live);
+			scatter(ws.cn_inSlotP, (slot << 2) + k, inP[k], live);
+			scatter(ws.cn_outSlotC, (slot << 2) + k, outC[k], live);
 		}
 	}
 }
 
-// the k-th in / out neighbour of band slot s (LDS copy, HBM beyond kNbr)
-template <int MAXN> GA_FN uint32_t in_neighbor(const GaDevGraph& g, const WaveState<MAXN>& ws, int s, int k)
+// where the k-th in-neighbour of band slot s sits in the current (cs) and the previous (pm) band, -1 = absent
+template <int MAXN> GA_FN void in_slots(const GaDevGraph& g, const WaveState<MAXN>& ws, int pn, int cn, int s, int k, int& cs, int& pm)
 {
-	if (ws.cn_inDeg[s] <= kNbr) return ws.cn_inNbr[s * kNbr + k];
-	return g.in_nbr[g.in_off[ws.cn_node[s]] + k];
+	if (ws.cn_inDeg[s] <= kNbr) { cs = ws.cn_inSlotC[s * kNbr + k]; pm = ws.cn_inSlotP[s * kNbr + k]; return; }
+	const uint32_t m = g.in_nbr[g.in_off[ws.cn_node[s]] + k];
+	cs = find_slot(ws.cn_node, cn, m);
+	pm = find_slot(ws.pn_node, pn, m);
+}
+// where the k-th out-neighbour of band slot s sits in the current band, -1 = absent
+template <int MAXN> GA_FN int out_slot(const GaDevGraph& g, const WaveState<MAXN>& ws, int cn, int s, int k)
+{
+	if (ws.cn_outDeg[s] <= kNbr) return ws.cn_outSlotC[s * kNbr + k];
+	return find_slot(ws.cn_node, cn, g.out_nbr[g.out_off[ws.cn_node[s]] + k]);
 }
 template <int MAXN> GA_FN int in_degree(const GaDevGraph& g, const WaveState<MAXN>& ws, int s)
 {
 	if (ws.cn_inDeg[s] <= kNbr) return ws.cn_inDeg[s];
 	return (int)(g.in_off[ws.cn_node[s] + 1] - g.in_off[ws.cn_node[s]]);
-}
-template <int MAXN> GA_FN uint32_t out_neighbor(const GaDevGraph& g, const WaveState<MAXN>& ws, int s, int k)
-{
-	if (ws.cn_outDeg[s] <= kNbr) return ws.cn_outNbr[s * kNbr + k];
-	return g.out_nbr[g.out_off[ws.cn_node[s]] + k];
 }
 template <int MAXN> GA_FN int out_degree(const GaDevGraph& g, const WaveState<MAXN>& ws, int s)
 {
@@ -346,7 +430,7 @@ template <int MAXN> GA_FN int processing_order(const GaDevGraph& g, WaveState<MA
 			int cur = (int)ws.st_cur[sp - 1];
 			if (cur < out_degree(g, ws, v))
 			{
-				int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, v, cur));
+				int x = out_slot(g, ws, cn, v, cur);
 				if (x < 0 || ws.color[x] == 2) { ws.st_cur[sp - 1] = (uint32_t)(cur + 1); continue; }
 				if (ws.color[x] == 1) return GA_UNSUPPORTED_CYCLE;
 				ws.color[x] = 1;
@@ -463,9 +547,8 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		bool hasIn = false;
 		for (int e = 0; e < inDeg; e++)
 		{
-			uint32_t m = in_neighbor(g, ws, s, e);
-			int cs = find_slot(ws.cn_node, cn, m);
-			int pm = find_slot(ws.pn_node, pn, m);
+			int cs, pm;
+			in_slots(g, ws, pn, cn, s, e, cs, pm);
 			if (cs < 0 && pm < 0) continue;
 			hasIn = true;
 			if (cs >= 0) zero0 = zero0 < ws.cn_lastBefore[cs] + 1 ? zero0 : ws.cn_lastBefore[cs] + 1;
@@ -492,9 +575,8 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			int calc = INF;
 			for (int e = 0; e < inDeg; e++)
 			{
-				uint32_t m = in_neighbor(g, ws, s, e);
-				int cs = find_slot(ws.cn_node, cn, m);
-				int pm = find_slot(ws.pn_node, pn, m);
+				int cs, pm;
+				in_slots(g, ws, pn, cn, s, e, cs, pm);
 				if (cs < 0 && pm < 0) continue;
 				VI leftT, eq;
 				int leftBefore;
@@ -842,7 +924,7 @@ template <int MAXN> GA_FN int scc_order(const GaDevGraph& g, WaveState<MAXN>& ws
 			const int cur = (int)ws.st_cur[sp - 1];
 			if (cur < out_degree(g, ws, v))
 			{
-				const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, v, cur));
+				const int x = out_slot(g, ws, cn, v, cur);
 				if (x >= 0 && ws.color[x] == 0) { open(x); continue; }
 				if (x >= 0 && ws.color[x] == 1 && index[x] < ws.low[v]) ws.low[v] = index[x];
 				ws.st_cur[sp - 1] = (uint32_t)(cur + 1);
@@ -891,9 +973,8 @@ GA_FN int zero_row_component(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 		const int inDeg = in_degree(g, ws, s);
 		for (int e = 0; e < inDeg; e++)
 		{
-			const uint32_t m = in_neighbor(g, ws, s, e);
-			const int cs = find_slot(ws.cn_node, cn, m);
-			const int pm = find_slot(ws.pn_node, pn, m);
+			int cs, pm;
+			in_slots(g, ws, pn, cn, s, e, cs, pm);
 			if (cs < 0 && pm < 0) continue;
 			if (cs >= 0 && ws.comp[cs] == ci) continue;
 			if (cs >= 0) zero0 = zero0 < ws.cn_lastBefore[cs] + 1 ? zero0 : ws.cn_lastBefore[cs] + 1;
@@ -918,7 +999,7 @@ GA_FN int zero_row_component(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 		const int outDeg = out_degree(g, ws, s);
 		for (int e = 0; e < outDeg; e++)
 		{
-			const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, s, e));
+			const int x = out_slot(g, ws, cn, s, e);
 			if (x < 0 || ws.comp[x] != ci) continue;
 			if (!heap_push(ws, heapSize, (uint32_t)x, carry + 1)) return GA_CAP_HEAP;
 		}
@@ -947,7 +1028,7 @@ GA_FN int zero_row_component(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 		const int outDeg = out_degree(g, ws, s);
 		for (int e = 0; e < outDeg; e++)
 		{
-			const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, s, e));
+			const int x = out_slot(g, ws, cn, s, e);
 			if (x < 0 || ws.comp[x] != ci) continue;
 			if (!heap_push(ws, heapSize, (uint32_t)x, score + (int)len)) return GA_CAP_HEAP;
 		}
@@ -1032,8 +1113,9 @@ GA_FN int fill_node_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot
 	bool source = true;
 	for (int e = 0; e < inDeg; e++)
 	{
-		const uint32_t m = in_neighbor(g, ws, s, e);
-		if (find_slot(ws.cn_node, cn, m) >= 0 || find_slot(ws.pn_node, pn, m) >= 0) { source = false; break; }
+		int cs, pm;
+		in_slots(g, ws, pn, cn, s, e, cs, pm);
+		if (cs >= 0 || pm >= 0) { source = false; break; }
 	}
 	GCol c;
 	if (source)
@@ -1055,9 +1137,8 @@ GA_FN int fill_node_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot
 		const bool aboveEq0 = aboveEqAt(base0);
 		for (int e = 0; e < inDeg; e++)
 		{
-			const uint32_t m = in_neighbor(g, ws, s, e);
-			const int cs = find_slot(ws.cn_node, cn, m);
-			const int pm = find_slot(ws.pn_node, pn, m);
+			int cs, pm;
+			in_slots(g, ws, pn, cn, s, e, cs, pm);
 			if (cs < 0 && pm < 0) continue;
 			uint64_t eqHere = eqOf[base0];
 			const bool haveAbove = pm >= 0;
@@ -1147,7 +1228,7 @@ GA_FN int fill_slice_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 				const int outDeg = out_degree(g, ws, s);
 				for (int e = 0; e < outDeg; e++)
 				{
-					const int x = find_slot(ws.cn_node, cn, out_neighbor(g, ws, s, e));
+					const int x = out_slot(g, ws, cn, s, e);
 					if (x < 0 || ws.comp[x] != ci || ws.color[x] != 0) continue;
 					if ((slot.end_cur[ws.cn_colBase[x]] & 127) < (uint32_t)W) { ws.st_slot[sp++] = (int16_t)x; ws.color[x] = 1; }
 				}
@@ -1298,7 +1379,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		if (st != GA_OK) return st;
 		if (totalCols > L.cap_cols) return GA_CAP_COLS;
 		wave_order();
-		load_topology(g, ws, cn);
+		load_topology(g, ws, pn, cn);
 		wave_order();
 		// this slice's row codes normally arrived during the previous slice; request the next slice's now
 		if (rowNextSlice != slice) rowNext = load_lanes(rows + (uint64_t)slice * W, W, 0);

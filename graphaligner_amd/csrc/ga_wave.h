@@ -68,6 +68,8 @@ inline VI vmin(const VI& a, int b) { return vmin(a, VI(b)); }
 inline VI select(const VB& c, const VI& a, const VI& b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VU select(const VB& c, const VU& a, const VU& b) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
 inline VI bit_extract(const VI& x, int bit) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (x.v[i] >> bit) & 1; return r; }
+// x mod B for a compile-time B (x >= 0)
+template <int B> inline VI vmod(const VI& x) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)((unsigned)x.v[i] % (unsigned)B); return r; }
 inline VI operator|(const VI& a, bool b) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = a.v[i] | (b ? 1 : 0); return r; }
 inline VI vpopc(const VU& a) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = __builtin_popcountll(a.v[i]); return r; }
 // bits 0..lane of a 64-bit word
@@ -133,6 +135,7 @@ GA_FN VI select(VB c, VI a, VI b) { return c ? a : b; }
 GA_FN VU select(VB c, VU a, VU b) { return c ? a : b; }
 GA_FN VI bit_extract(VI x, int bit) { return (int)__builtin_amdgcn_ubfe((unsigned)x, (unsigned)bit, 1u); }
 GA_FN VI vpopc(VU a) { return __builtin_popcountll(a); }
+template <int B> GA_FN VI vmod(VI x) { return (int)((unsigned)x % (unsigned)B); }      // constant divisor: a multiply-high and a subtract
 GA_FN VU low_mask_through_lane() { return threadIdx.x == 63 ? ~0ull : ((2ull << threadIdx.x) - 1); }
 
 // v_mov_b32 dpp wave_shr:1 -- lane 0 has no source lane and keeps `fill`

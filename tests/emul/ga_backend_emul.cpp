@@ -124,6 +124,15 @@ extern "C" int ga_emul_hash_order(const uint32_t* keys, int n, int32_t* out)
 	return n;
 }
 
+extern "C" int ga_emul_hash_order_lanes(const uint32_t* keys, int n, int32_t* out)
+{
+	auto ws = std::make_unique<gak::WaveState<64>>();
+	if (n > 64) return -1;
+	gak::hash_order_lanes(*ws, keys, n);
+	for (int i = 0; i < n; i++) out[i] = ws->h_order[i];
+	return n;
+}
+
 // push (node, prio) pairs then pop everything; ops: prio >= 0 push, prio < 0 pop.  returns pop order
 extern "C" int ga_emul_heap(const uint32_t* nodes, const int32_t* prios, int nOps, uint32_t* popped)
 {

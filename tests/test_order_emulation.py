@@ -25,8 +25,8 @@ def test_hash_iteration_order(emul):
     L.gao_frozen_order.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     rng = np.random.default_rng(11)
     ref = ob.reflib()
-    for trial in range(200):
-        n = int(rng.integers(1, 257))
+    for trial in range(400):
+        n = int(rng.integers(1, 257)) if trial % 2 else int(rng.integers(1, 65))
         universe = int(rng.choice([300, 5000, 200000]))
         keys = rng.choice(universe, size=n, replace=False).astype(np.uint32)
         out = np.zeros(n, dtype=np.int32)
@@ -35,6 +35,11 @@ def test_hash_iteration_order(emul):
         o = np.zeros(n, dtype=np.int64)
         assert L.gao_frozen_order(ob._p(k64), n, universe, ob._p(o)) == n
         assert (keys[out] == o).all()
+        if n <= 64:
+            # the lane-parallel form used for bands of up to 64 nodes
+            out2 = np.zeros(n, dtype=np.int32)
+            assert emul.ga_emul_hash_order_lanes(keys.ctypes.data_as(C.c_void_p), n, out2.ctypes.data_as(C.c_void_p)) == n
+            assert (out2 == out).all(), (n, keys, out, out2)
         if ref is not None and trial % 8 == 0:
             o2 = np.zeros(n, dtype=np.int64)
             assert ref.ref_frozen_order(ob._p(k64), n, universe, ob._p(o2)) == n
