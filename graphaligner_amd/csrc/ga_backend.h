@@ -17,6 +17,30 @@ struct GaFlatGraph                      // host copy of what goes to HBM
 	std::vector<uint32_t> in_off, in_nbr, out_off, out_nbr;
 };
 
+// the per-node records of GaDevGraph::node_rec
+inline std::vector<uint32_t> ga_build_node_records(const GaFlatGraph& f)
+{
+	const size_t n = f.node_start.size() - 1;
+	std::vector<uint32_t> rec(n * GA_NODE_REC_WORDS, 0);
+	for (size_t i = 0; i < n; i++)
+	{
+		uint32_t* r = rec.data() + i * GA_NODE_REC_WORDS;
+		r[0] = (uint32_t)f.node_start[i];
+		r[1] = (uint32_t)(f.node_start[i] >> 32);
+		r[2] = (uint32_t)(f.node_start[i + 1] - f.node_start[i]);
+		const uint32_t inDeg = f.in_off[i + 1] - f.in_off[i], outDeg = f.out_off[i + 1] - f.out_off[i];
+		r[3] = (inDeg < 0xffffu ? inDeg : 0xffffu) | ((outDeg < 0xffffu ? outDeg : 0xffffu) << 16);
+		for (uint32_t k = 0; k < 4 && k < outDeg; k++) r[4 + k] = f.out_nbr[f.out_off[i] + k];
+		for (uint32_t k = 0; k < 4 && k < inDeg; k++)
+		{
+			const uint32_t m = f.in_nbr[f.in_off[i] + k];
+			r[8 + k] = m;
+			r[12 + k] = (uint32_t)(f.node_start[m + 1] - f.node_start[m]);
+		}
+	}
+	return rec;
+}
+
 struct GaRunConfig
 {
 	int initial_bw = 0, ramp_bw = 0;

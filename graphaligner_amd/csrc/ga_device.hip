@@ -300,6 +300,7 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	bad |= g->put(flat.in_nbr, &g->g.in_nbr);
 	bad |= g->put(flat.out_off, &g->g.out_off);
 	bad |= g->put(flat.out_nbr, &g->g.out_nbr);
+	bad |= g->put(ga_build_node_records(flat), &g->g.node_rec);
 	std::vector<GaHmmTables> h(1, hmm);
 	const GaHmmTables* dh = nullptr;
 	bad |= g->put(h, &dh);

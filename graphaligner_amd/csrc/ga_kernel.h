@@ -100,7 +100,9 @@ struct Slot
 GA_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 
 // ---- graph access (wave-uniform) -------------------------------------------------------------
-GA_FN uint32_t g_len(const GaDevGraph& g, uint32_t n) { return (uint32_t)(g.node_start[n + 1] - g.node_start[n]); }
+GA_FN uint32_t g_len(const GaDevGraph& g, uint32_t n) { return g.node_rec[(uint64_t)n * GA_NODE_REC_WORDS + 2]; }
+// the node's 64-byte record, one word per lane (lanes 0..15): a single request
+GA_FN VI g_record(const GaDevGraph& g, uint32_t n) { return load_lanes(g.node_rec + (uint64_t)n * GA_NODE_REC_WORDS, GA_NODE_REC_WORDS, 0); }
 GA_FN int g_base(const GaDevGraph& g, uint64_t col) { return (int)((g.seq2[col >> 4] >> ((col & 15) * 2)) & 3); }
 
 // slot of `key` in list[0..count) or -1: 64 entries per step, one ballot
@@ -254,6 +256,65 @@ template <int MAXN> GA_FN void heap_pop(WaveState<MAXN>& ws, int& size)
 	heap_sift_up(ws, hole, 0, node, prio);
 }
 
+// The same heap with its array spread over the lanes of a few registers (entry k = lane k & 63 of register k >> 6):
+// a sift then costs v_readlane / v_writelane moves instead of dependent LDS round trips.  Used while the heap fits.
+template <int NREG> struct LaneHeap
+{
+	VI node[NREG], prio[NREG];
+	GA_FN int getPrio(int k) const { VI v = prio[0]; for (int i = 1; i < NREG; i++) if ((k >> 6) == i) v = prio[i]; return read_lane(v, k & 63); }
+	GA_FN int getNode(int k) const { VI v = node[0]; for (int i = 1; i < NREG; i++) if ((k >> 6) == i) v = node[i]; return read_lane(v, k & 63); }
+	GA_FN void set(int k, int n, int p)
+	{
+		for (int i = 0; i < NREG; i++)
+			if ((k >> 6) == i) { node[i] = write_lane(node[i], n, k & 63); prio[i] = write_lane(prio[i], p, k & 63); }
+	}
+	GA_FN void siftUp(int hole, int n, int p)
+	{
+		int parent = (hole - 1) / 2;
+		while (hole > 0)
+		{
+			const int pp = getPrio(parent);
+			if (!(pp > p)) break;
+			set(hole, getNode(parent), pp);
+			hole = parent;
+			parent = (hole - 1) / 2;
+		}
+		set(hole, n, p);
+	}
+	GA_FN bool push(int& size, uint32_t n, int p)
+	{
+		if (size >= NREG * LANES) return false;
+		size++;
+		siftUp(size - 1, (int)n, p);
+		return true;
+	}
+	GA_FN void pop(int& size)
+	{
+		// std::pop_heap then pop_back: the last element is re-inserted from the root (__adjust_heap)
+		const int len = size - 1;
+		const int n = getNode(len), p = getPrio(len);
+		size = len;
+		if (len == 0) return;
+		int hole = 0, child = 0;
+		while (child < (len - 1) / 2)
+		{
+			child = 2 * (child + 1);
+			int cp = getPrio(child);
+			const int lp = getPrio(child - 1);
+			if (cp > lp) { child--; cp = lp; }
+			set(hole, getNode(child), cp);
+			hole = child;
+		}
+		if ((len & 1) == 0 && child == (len - 2) / 2)
+		{
+			child = 2 * (child + 1);
+			set(hole, getNode(child - 1), getPrio(child - 1));
+			hole = child - 1;
+		}
+		siftUp(hole, n, p);
+	}
+};
+
 // ---- band selection at node granularity (GraphAligner.h:1110-1159) ---------------------------------
 template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>& ws, int pn, int prevMin, int bandwidth, int& cn, uint32_t& totalCols)
 {
@@ -261,6 +322,13 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 	cn = 0;
 	totalCols = 0;
 	int heapSize = 0;
+	constexpr bool kLaneHeap = Limits<MAXN>::kHeap <= 4 * LANES;
+	LaneHeap<kLaneHeap ? Limits<MAXN>::kHeap / LANES : 1> lh;
+	if constexpr (kLaneHeap) for (int i = 0; i < Limits<MAXN>::kHeap / LANES; i++) { lh.node[i] = VI(0); lh.prio[i] = VI(0); }
+	auto push = [&](uint32_t node, int prio) -> bool {
+		if constexpr (kLaneHeap) return lh.push(heapSize, node, prio);
+		else return heap_push(ws, heapSize, node, prio);
+	};
 	if (pn <= LANES) hash_order_lanes(ws, ws.pn_node, pn); else hash_order(ws, ws.pn_node, pn);
 	auto add = [&](uint32_t node, int prevSlot, uint32_t len) -> bool {
 		if (cn >= MAXN) return false;
@@ -270,6 +338,16 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 		ws.cn_colBase[cn] = totalCols;
 		totalCols += len;
 		cn++;
+		return true;
+	};
+	auto pushFromGraph = [&](const VI& rec, uint32_t node, int prio) -> bool {
+		const uint32_t deg = (uint32_t)read_lane(rec, 3) >> 16;
+		if (deg <= (uint32_t)kNbr)
+		{
+			for (uint32_t e = 0; e < deg; e++) if (!push((uint32_t)read_lane(rec, 4 + (int)e), prio)) return false;
+			return true;
+		}
+		for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++) if (!push(g.out_nbr[e], prio)) return false;
 		return true;
 	};
 	for (int k = 0; k < pn; k++)
@@ -285,35 +363,37 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 		if (deg <= kNbr)
 		{
 			for (int e = 0; e < deg; e++)
-				if (!heap_push(ws, heapSize, ws.pn_outNbr[s * kNbr + e], endScore - prevMin + 1)) return GA_CAP_HEAP;
+				if (!push(ws.pn_outNbr[s * kNbr + e], endScore - prevMin + 1)) return GA_CAP_HEAP;
 		}
-		else
-		{
-			for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
-				if (!heap_push(ws, heapSize, g.out_nbr[e], endScore - prevMin + 1)) return GA_CAP_HEAP;
-		}
+		else if (!pushFromGraph(g_record(g, node), node, endScore - prevMin + 1)) return GA_CAP_HEAP;
 	}
 	if (cn == 0) return GA_ASSERTION;                                   // assert(distances.size() > 0) (:1138)
 	while (heapSize > 0)
 	{
-		uint32_t node = ws.heap_node[0];
-		int prio = ws.heap_prio[0];
+		uint32_t node;
+		int prio;
+		if constexpr (kLaneHeap) { node = (uint32_t)lh.getNode(0); prio = lh.getPrio(0); }
+		else { node = ws.heap_node[0]; prio = ws.heap_prio[0]; }
 		if (prio > expand) break;
-		heap_pop(ws, heapSize);
+		if constexpr (kLaneHeap) lh.pop(heapSize); else heap_pop(ws, heapSize);
 		if (find_slot(ws.cn_node, cn, node) >= 0) continue;             // already at a distance <= prio
 		int ps = find_slot(ws.pn_node, pn, node);
-		uint32_t len = ps >= 0 ? ws.pn_len[ps] : g_len(g, node);
-		if (!add(node, ps, len)) return GA_CAP_NODES;
-		if (totalCols >= kCutoff) return GA_UNSUPPORTED_BAND;
 		if (ps >= 0 && ws.pn_outDeg[ps] <= kNbr)
 		{
+			const uint32_t len = ws.pn_len[ps];
+			if (!add(node, ps, len)) return GA_CAP_NODES;
+			if (totalCols >= kCutoff) return GA_UNSUPPORTED_BAND;
 			for (int e = 0; e < ws.pn_outDeg[ps]; e++)
-				if (!heap_push(ws, heapSize, ws.pn_outNbr[ps * kNbr + e], prio + (int)len)) return GA_CAP_HEAP;
+				if (!push(ws.pn_outNbr[ps * kNbr + e], prio + (int)len)) return GA_CAP_HEAP;
 		}
 		else
 		{
-			for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++)
-				if (!heap_push(ws, heapSize, g.out_nbr[e], prio + (int)len)) return GA_CAP_HEAP;
+			// a node new to the band: its length and out-list arrive together in its record
+			const VI rec = g_record(g, node);
+			const uint32_t len = (uint32_t)read_lane(rec, 2);
+			if (!add(node, ps, len)) return GA_CAP_NODES;
+			if (totalCols >= kCutoff) return GA_UNSUPPORTED_BAND;
+			if (!pushFromGraph(rec, node, prio + (int)len)) return GA_CAP_HEAP;
 		}
 	}
 	return GA_OK;
@@ -326,17 +406,16 @@ template <int MAXN> GA_FN int project_band(const GaDevGraph& g, WaveState<MAXN>&
 template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN>& ws, int pn, int cn)
 {
 	const VI lane = lane_iota();
-	const uint32_t* startWords = (const uint32_t*)g.node_start;
 	for (int base = 0; base < cn; base += LANES)
 	{
 		VB live = lane < (cn - base);
 		VI slot = lane + base;
 		VI node = select(live, load_lanes(ws.cn_node + base, cn - base, 0), VI(0));
-		VI lo = gather(startWords, node + node);
-		VI hi = gather(startWords, node + node + 1);
-		VI in0 = gather(g.in_off, node), in1 = gather(g.in_off, node + 1);
-		VI out0 = gather(g.out_off, node), out1 = gather(g.out_off, node + 1);
-		VI inDeg = in1 - in0, outDeg = out1 - out0;
+		const VI at = node << 4;                                           // GA_NODE_REC_WORDS = 16
+		VI lo = gather(g.node_rec, at);
+		VI hi = gather(g.node_rec, at + 1);
+		VI degs = gather(g.node_rec, at + 3);
+		VI inDeg = degs & 0xffff, outDeg = (degs >> 16) & 0xffff;
 		scatter(ws.cn_startLo, slot, lo, live);
 		scatter(ws.cn_startHi, slot, hi, live);
 		scatter(ws.cn_inDeg, slot, vmin(inDeg, VI(255)), live);
@@ -346,8 +425,8 @@ template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN
 		{
 			VB hasIn = live && (VI(k) < inDeg);
 			VB hasOut = live && (VI(k) < outDeg);
-			inN[k] = select(hasIn, gather(g.in_nbr, select(hasIn, in0 + k, VI(0))), VI(-1));
-			outN[k] = select(hasOut, gather(g.out_nbr, select(hasOut, out0 + k, VI(0))), VI(-1));
+			inN[k] = select(hasIn, gather(g.node_rec, at + (8 + k)), VI(-1));
+			outN[k] = select(hasOut, gather(g.node_rec, at + (4 + k)), VI(-1));
 			scatter(ws.cn_outNbr, (slot << 2) + k, outN[k], hasOut);
 			inC[k] = VI(-1); inP[k] = VI(-1); outC[k] = VI(-1);
 		}
@@ -1268,13 +1347,12 @@ GA_FN int fill_slice_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 }
 
 // ---- cell value from the stored words (WordSlice.h:223-229; getValueOrMax GraphAligner.h:2008-2017) ------
-struct SliceView { const uint32_t* arena; const uint32_t* slice_off; };
-
-GA_FN int stored_value(const SliceRec& r, uint32_t nNodes, uint32_t node, uint32_t offset, int rowInSlice, int big)
+// the band node list of the slice being traced is kept in LDS (tabNodes / tabBase), so finding a node costs no memory round trip
+GA_FN int stored_value(const SliceRec& r, const uint32_t* tabNodes, const uint32_t* tabBase, uint32_t nNodes, uint32_t node, uint32_t offset, int rowInSlice, int big)
 {
-	int slot = find_slot(r.nodes, (int)nNodes, node);
+	int slot = find_slot(tabNodes, (int)nNodes, node);
 	if (slot < 0) return big;
-	uint32_t idx = r.colBase[slot] + offset;
+	uint32_t idx = tabBase[slot] + offset;
 	uint64_t vp = r.vp[idx], vn = r.vn[idx];
 	uint64_t mask = rowInSlice < 63 ? ~(~0ull << (rowInSlice + 1)) : ~0ull;
 	return r.before[idx] + __builtin_popcountll(vp & mask) - __builtin_popcountll(vn & mask);
@@ -1647,17 +1725,32 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		out.start_node = node; out.start_offset = offset; out.start_row = row;
 		SliceRec prv = cur;
 		uint32_t pN = 0;
+		// node lists (node id, first column in the record) of the slice traced through and of the one above it, in LDS
+		uint32_t* curNodes = ws.cn_node; uint32_t* curBase = ws.cn_colBase;
+		uint32_t* prvNodes = ws.pn_node; uint32_t* prvBase = ws.pn_colBase;
+		auto loadTable = [&](uint32_t* tn, uint32_t* tb, const SliceRec& r, uint32_t n) {
+			wave_order();
+			for (uint32_t c = 0; c < n; c += LANES)
+			{
+				store_lanes(tn + c, (int)(n - c), load_lanes(r.nodes + c, (int)(n - c), 0));
+				store_lanes(tb + c, (int)(n - c), load_lanes(r.colBase + c, (int)(n - c), 0));
+			}
+			wave_order();
+		};
 		auto loadPrev = [&]() {
 			if (sIdx == 0) return;
 			uint32_t o = belowTab[sIdx - 1];
 			pN = slot.arena[o];
 			prv = slice_at(slot.arena, o, pN, slot.arena[o + 1]);
+			loadTable(prvNodes, prvBase, prv, pN);
 		};
+		wave_sync();
+		loadTable(curNodes, curBase, cur, nN);
 		loadPrev();
 		auto valuePrevLastRow = [&](uint32_t n, uint32_t o2) -> int {
 			// row 63 of the slice before; before slice 0 that is the all-zero seed slice
 			if (sIdx == 0) return n == job.seed_node ? 0 : big;
-			return stored_value(prv, pN, n, o2, W - 1, big);
+			return stored_value(prv, prvNodes, prvBase, pN, n, o2, W - 1, big);
 		};
 		// A window = up to 64 consecutive columns of one node in one slice, one column per lane, so a
 		// run of steps inside a node costs no memory round trips: every lane evaluates its column
@@ -1671,16 +1764,18 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		VI rowv = load_lanes(rows + sIdx * W, W, 0);
 		uint32_t rowvSlice = sIdx;
 		const VI lane = lane_iota();
-		auto loadWindow = [&](Window& w, const SliceRec& rec, uint32_t recNodes, uint32_t sliceIdx, uint32_t n, uint32_t hiOffset) {
+		VI winRec = VI(0);                         // graph record of the node the current window lies in
+		uint32_t winRecNode = 0xffffffffu;
+		auto loadWindow = [&](Window& w, const SliceRec& rec, const uint32_t* tn, const uint32_t* tb, uint32_t recNodes, uint32_t sliceIdx, uint32_t n, uint32_t hiOffset) {
 			w.slice = sliceIdx; w.node = n;
 			w.lo = hiOffset >= (uint32_t)(LANES - 1) ? (int)(hiOffset - (LANES - 1)) : 0;
 			w.n = (int)hiOffset - w.lo + 1;
-			int sl = find_slot(rec.nodes, (int)recNodes, n);
+			int sl = find_slot(tn, (int)recNodes, n);
 			w.present = sl >= 0;
 			w.valid = true;
 			if (sl >= 0)
 			{
-				uint32_t at = rec.colBase[sl] + (uint32_t)w.lo;
+				uint32_t at = tb[sl] + (uint32_t)w.lo;
 				w.vp = load_lanes_u64(rec.vp + at, w.n);
 				w.vn = load_lanes_u64(rec.vn + at, w.n);
 				w.before = load_lanes(rec.before + at, w.n, 0);
@@ -1702,13 +1797,15 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				}
 				else
 				{
-					loadWindow(cw, cur, nN, sIdx, node, offset);
-					const uint64_t firstCol = g.node_start[node] + (uint32_t)cw.lo;
+					if (winRecNode != node) { winRec = g_record(g, node); winRecNode = node; }      // travels together with the window's words
+					loadWindow(cw, cur, curNodes, curBase, nN, sIdx, node, offset);
+					const uint64_t firstCol = (((uint64_t)(uint32_t)read_lane(winRec, 1) << 32) | (uint32_t)read_lane(winRec, 0)) + (uint32_t)cw.lo;
 					VI at = lane + (int)(firstCol & 15);
 					winBases = (gather(g.seq2 + (firstCol >> 4), at >> 4) >> ((at & 15) << 1)) & 3;
 				}
 				pw.valid = false;
 			}
+			if (winRecNode != node) { winRec = g_record(g, node); winRecNode = node; }
 			if (!cw.present) { status = GA_ASSERTION; break; }                   // assert(slice.scores.hasNode(nodeIndex)) (:498)
 			const int rel = (int)offset - cw.lo;
 			const uint64_t maskR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull;
@@ -1759,7 +1856,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			else
 			{
 				if (!(pw.valid && pw.slice == sIdx - 1 && pw.node == node && pw.lo == cw.lo && pw.n == cw.n))
-					loadWindow(pw, prv, pN, sIdx - 1, node, (uint32_t)(cw.lo + cw.n - 1));
+					loadWindow(pw, prv, prvNodes, prvBase, pN, sIdx - 1, node, (uint32_t)(cw.lo + cw.n - 1));
 				if (pw.present) valUp = pw.before + vpopc(pw.vp) - vpopc(pw.vn);
 				else valUp = VI(big);
 			}
@@ -1784,15 +1881,61 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			};
 			if (curOffset == 0)
 			{
-				for (uint32_t e = g.in_off[curNode]; e < g.in_off[curNode + 1] && res == 0; e++)
+				const int inDeg = read_lane(winRec, 3) & 0xffff;
+				if (inDeg <= kNbr)
 				{
-					uint32_t m = g.in_nbr[e];
-					uint32_t mo = g_len(g, m) - 1;
-					viaNeighbour = (int)(e - g.in_off[curNode]);
-					int horizontal = stored_value(cur, nN, m, mo, r, big);
-					int diagonal = 0;
-					if (horizontal > here - 1) diagonal = r == 0 ? valuePrevLastRow(m, mo) : stored_value(cur, nN, m, mo, r - 1, big);
-					res = decide(horizontal, diagonal, m, mo);
+					// the last columns of all in-neighbours (this slice, and the slice above when at its first row) in one round trip:
+					// lane k < inDeg looks at in-neighbour k; the record holds the neighbours and their lengths
+					const VI nbr = lane_gather(winRec, vmin(lane, VI(kNbr - 1)) + 8);
+					const VI nbrLast = lane_gather(winRec, vmin(lane, VI(kNbr - 1)) + 12) - 1;
+					VI idxCur = VI(-1), idxPrv = VI(-1);
+					for (int k = 0; k < inDeg; k++)
+					{
+						const uint32_t m = (uint32_t)read_lane(nbr, k);
+						const int sc = find_slot(curNodes, (int)nN, m);
+						if (sc >= 0) idxCur = select(lane == k, VI((int)curBase[sc]) + nbrLast, idxCur);
+						if (r == 0 && sIdx > 0)
+						{
+							const int sp = find_slot(prvNodes, (int)pN, m);
+							if (sp >= 0) idxPrv = select(lane == k, VI((int)prvBase[sp]) + nbrLast, idxPrv);
+						}
+					}
+					const VB haveC = idxCur > -1;
+					const VI safeC = select(haveC, idxCur, VI(0));
+					const VU vpC = select(haveC, gather64(cur.vp, safeC), VU(0)), vnC = select(haveC, gather64(cur.vn, safeC), VU(0));
+					const VI beC = gather(cur.before, safeC);
+					const VI horV = select(haveC, beC + vpopc(vpC & VU(maskR)) - vpopc(vnC & VU(maskR)), VI(big));
+					VI diaV;
+					if (r > 0)
+					{
+						const uint64_t maskU = ~(~0ull << r);
+						diaV = select(haveC, beC + vpopc(vpC & VU(maskU)) - vpopc(vnC & VU(maskU)), VI(big));
+					}
+					else if (sIdx == 0) diaV = select(nbr == (int)job.seed_node, VI(0), VI(big));
+					else
+					{
+						const VB haveP = idxPrv > -1;
+						const VI safeP = select(haveP, idxPrv, VI(0));
+						diaV = select(haveP, gather(prv.before, safeP) + vpopc(gather64(prv.vp, safeP)) - vpopc(gather64(prv.vn, safeP)), VI(big));
+					}
+					for (int k = 0; k < inDeg && res == 0; k++)
+					{
+						viaNeighbour = k;
+						res = decide(read_lane(horV, k), read_lane(diaV, k), (uint32_t)read_lane(nbr, k), (uint32_t)read_lane(nbrLast, k));
+					}
+				}
+				else
+				{
+					for (uint32_t e = g.in_off[curNode]; e < g.in_off[curNode + 1] && res == 0; e++)
+					{
+						uint32_t m = g.in_nbr[e];
+						uint32_t mo = g_len(g, m) - 1;
+						viaNeighbour = (int)(e - g.in_off[curNode]);
+						int horizontal = stored_value(cur, curNodes, curBase, nN, m, mo, r, big);
+						int diagonal = 0;
+						if (horizontal > here - 1) diagonal = r == 0 ? valuePrevLastRow(m, mo) : stored_value(cur, curNodes, curBase, nN, m, mo, r - 1, big);
+						res = decide(horizontal, diagonal, m, mo);
+					}
 				}
 			}
 			else res = decide(read_lane(valR, rel - 1), read_lane(valUp, rel - 1), curNode, curOffset - 1);
@@ -1816,13 +1959,19 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			{
 				// stepped into the slice above
 				sIdx--;
-				if (belowTab[sIdx] == inTab[sIdx]) { cur = prv; nN = pN; }
+				if (belowTab[sIdx] == inTab[sIdx])
+				{
+					cur = prv; nN = pN;
+					uint32_t* t = curNodes; curNodes = prvNodes; prvNodes = t;
+					t = curBase; curBase = prvBase; prvBase = t;
+				}
 				else
 				{
 					// the slice is traced through in another version than the one the boundary step looked at
 					const uint32_t o = inTab[sIdx];
 					nN = slot.arena[o];
 					cur = slice_at(slot.arena, o, nN, slot.arena[o + 1]);
+					loadTable(curNodes, curBase, cur, nN);
 					pw.valid = false;
 				}
 				loadPrev();

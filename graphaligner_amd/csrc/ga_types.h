@@ -27,7 +27,12 @@ struct GaDevGraph {
 	const uint32_t* in_nbr;      // in-neighbours in insertion order (AlignmentGraph.cpp:104)
 	const uint32_t* out_off;     // [n_nodes + 1]
 	const uint32_t* out_nbr;     // out-neighbours in insertion order (AlignmentGraph.cpp:105)
+	// one 64-byte record per node so that everything a band step needs about a node arrives with one request:
+	// [0..1] first column, [2] length, [3] in-degree | out-degree << 16 (capped at 0xffff),
+	// [4..7] first four out-neighbours, [8..11] first four in-neighbours, [12..15] the lengths of those in-neighbours
+	const uint32_t* node_rec;
 };
+#define GA_NODE_REC_WORDS 16
 
 // log-space Viterbi constants, computed on the host with the same libm calls in the same
 // order as AlignmentCorrectnessEstimation.cpp:6-36,81-83; the device only adds and compares.

@@ -101,6 +101,7 @@ inline void store_lanes(uint64_t* p, int count, const VU& x) { for (int i = 0; i
 inline VU load_lanes_u64(const uint64_t* p, int count) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = i < count ? p[i] : 0; return r; }
 // per-lane indexed load / masked indexed store
 template <typename T> inline VI gather(const T* p, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)p[idx.v[i]]; return r; }
+inline VU gather64(const uint64_t* p, const VI& idx) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = p[idx.v[i]]; return r; }
 template <typename T> inline void scatter(T* p, const VI& idx, const VI& x, const VB& m) { for (int i = 0; i < LANES; i++) if (m.v[i]) p[idx.v[i]] = (T)x.v[i]; }
 inline void wave_sync() {}
 inline void wave_order() {}
@@ -190,6 +191,7 @@ template <typename T> GA_FN void store_lanes(T* p, int count, VI x) { if ((int)t
 GA_FN void store_lanes(uint64_t* p, int count, VU x) { if ((int)threadIdx.x < count) p[threadIdx.x] = x; }
 GA_FN VU load_lanes_u64(const uint64_t* p, int count) { return (int)threadIdx.x < count ? p[threadIdx.x] : 0ull; }
 template <typename T> GA_FN VI gather(const T* p, VI idx) { return (int)p[idx]; }
+GA_FN VU gather64(const uint64_t* p, VI idx) { return p[idx]; }
 template <typename T> GA_FN void scatter(T* p, VI idx, VI x, VB m) { if (m) p[idx] = (T)x; }
 // one wave per workgroup: orders this wave's LDS / global traffic (s_waitcnt + s_barrier)
 GA_FN void wave_sync() { __syncthreads(); }

@@ -20,6 +20,7 @@ namespace {
 struct EmulGraph : GaBackendGraph
 {
 	GaFlatGraph flat;
+	std::vector<uint32_t> nodeRec;
 	GaHmmTables hmm;
 	GaDevGraph dev;
 };
@@ -99,6 +100,8 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	g->dev.in_nbr = g->flat.in_nbr.data();
 	g->dev.out_off = g->flat.out_off.data();
 	g->dev.out_nbr = g->flat.out_nbr.data();
+	g->nodeRec = ga_build_node_records(g->flat);
+	g->dev.node_rec = g->nodeRec.data();
 	*status = 0;
 	return g;
 }
@@ -131,6 +134,21 @@ extern "C" int ga_emul_hash_order_lanes(const uint32_t* keys, int n, int32_t* ou
 	gak::hash_order_lanes(*ws, keys, n);
 	for (int i = 0; i < n; i++) out[i] = ws->h_order[i];
 	return n;
+}
+
+// the same through the lane-resident heap
+extern "C" int ga_emul_heap_lanes(const uint32_t* nodes, const int32_t* prios, int nOps, uint32_t* popped)
+{
+	gak::LaneHeap<4> h;
+	for (int i = 0; i < 4; i++) { h.node[i] = gaw::VI(0); h.prio[i] = gaw::VI(0); }
+	int size = 0, k = 0;
+	for (int i = 0; i < nOps; i++)
+	{
+		if (prios[i] >= 0) { if (!h.push(size, nodes[i], prios[i])) return -1; }
+		else if (size > 0) { popped[k++] = (uint32_t)h.getNode(0); h.pop(size); }
+	}
+	while (size > 0) { popped[k++] = (uint32_t)h.getNode(0); h.pop(size); }
+	return k;
 }
 
 // push (node, prio) pairs then pop everything; ops: prio >= 0 push, prio < 0 pop.  returns pop order

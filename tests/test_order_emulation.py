@@ -61,4 +61,8 @@ def test_priority_queue_tie_order(emul):
         ka = emul.ga_emul_heap(nodes.ctypes.data_as(C.c_void_p), prios.ctypes.data_as(C.c_void_p), n_ops, a.ctypes.data_as(C.c_void_p))
         kb = L.gao_pq_order(nodes.ctypes.data_as(C.c_void_p), prios.ctypes.data_as(C.c_void_p), n_ops, b.ctypes.data_as(C.c_void_p))
         assert ka == kb
+        if ka >= 0 and int((prios >= 0).sum()) <= 256:
+            c = np.zeros(n_ops, dtype=np.uint32)
+            kc = emul.ga_emul_heap_lanes(nodes.ctypes.data_as(C.c_void_p), prios.ctypes.data_as(C.c_void_p), n_ops, c.ctypes.data_as(C.c_void_p))
+            assert kc == ka and (c[:kc] == a[:ka]).all()
         assert (a[:ka] == b[:kb]).all()
