@@ -25,34 +25,49 @@ def main():
     import parity_common as pc
     lib = pc.emul_lib_path() if args.emul else None
     rng = np.random.default_rng(args.seed)
-    stats = dict(reads=0, compared=0, mismatches=0, dev_status={}, first_mismatches=[])
+    stats = dict(reads=0, compared=0, mismatches=0, cyclic_trials=0, ramp_trials=0, dev_status={}, first_mismatches=[])
     t0 = time.time()
     for trial in range(args.trials):
         nl = int(rng.choice([3, 8, 16, 32, 64, 100]))
         snp = int(rng.choice([0, 25, 60, 100]))
         indel = int(rng.choice([0, 100, 400, 1000]))
         sv = int(rng.choice([0, 0, 2500]))
-        g = synth.SynthGraph(synth.random_genome(int(rng.choice([6000, 15000, 40000])), 7000 + trial), node_len=nl, snp_every=snp, indel_every=indel, sv_every=sv, seed=trial)
         L = int(rng.choice([300, 700, 1500, 3000, 6000]))
         bw = int(rng.choice([2, 8, 20, 35, 35, 35, 50, 90]))
         err = float(rng.choice([0.0, 0.01, 0.04, 0.04, 0.08]))
         mid = bool(rng.random() < 0.4)
+        cyclic = trial % 3 == 1          # tandem-repeat back edges and self loops: bands with strongly connected components
+        ramp = 0
+        if trial % 4 == 2:               # -B: narrow band first, ramp width on demand (damaged reads make the HMM flip)
+            bw = int(rng.choice([3, 5, 10, 15]))
+            ramp = bw + int(rng.choice([15, 30, 60]))
         try:
-            reads, seeds = synth.simulate_reads(g, args.reads, L, sub=err, ins=err, dele=err, seed=trial, mid_seed=mid)
+            if cyclic:
+                g = synth.cyclic_graph(int(rng.choice([4000, 9000])), node_len=max(nl, 4), seed=trial, back_edges=int(rng.integers(2, 12)), self_loops=int(rng.integers(0, 4)),
+                                       max_span=int(rng.integers(1, 9)), snp_every=snp if snp else 60)
+                reads, seeds = synth.walk_reads(g, args.reads, min(L, 3000), sub=err, ins=err, dele=err, seed=trial, mid_seed=mid, first_nodes=max(1, len(g.nodes) // 3))
+            else:
+                g = synth.SynthGraph(synth.random_genome(int(rng.choice([6000, 15000, 40000])), 7000 + trial), node_len=nl, snp_every=snp, indel_every=indel, sv_every=sv, seed=trial)
+                reads, seeds = synth.simulate_reads(g, args.reads, L, sub=err, ins=err, dele=err, seed=trial, mid_seed=mid)
         except RuntimeError:
             continue
+        stats["cyclic_trials"] += int(cyclic)
+        stats["ramp_trials"] += int(ramp > 0)
+        if ramp:
+            import parity_cases
+            reads = parity_cases.damaged_reads(reads, rng)
         # sprinkle IUPAC / N / lower case into some reads
         for k in range(0, len(reads), 5):
             b = bytearray(reads[k].encode())
             for _ in range(8):
                 b[int(rng.integers(len(b)))] = ord("NRYKMSWBDVnacgt"[int(rng.integers(15))])
             reads[k] = b.decode()
-        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, lib_path=lib)
+        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, ramp=ramp, lib_path=lib)
         for i, (d, o) in enumerate(zip(devs, oras)):
             stats["reads"] += 1
             stats["dev_status"][str(d["status"])] = stats["dev_status"].get(str(d["status"]), 0) + 1
-            if d["status"] in (10, 20, 21):
-                continue      # reported as unsupported / capacity: never a silently different answer
+            if d["status"] in (10, 11, 12, 13, 14):
+                continue      # band beyond the widest kernel variant: reported as a capacity status, never a silently different answer
             stats["compared"] += 1
             try:
                 pc.compare_read(d, o, "trial %d read %d" % (trial, i))
