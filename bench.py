@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_COLUMN_UPDATE = 28.0      # 0.25 base + 4 prev end + 4 end out + 20 VP/VN/score
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_STREAM_GBS = 5318.6             # what a streaming copy reaches on this pool (profiles/r1_hbm_stream.txt, tools/hbm_stream.hip)
 
 
 def main():
@@ -148,7 +149,7 @@ def main():
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "bandwidth": args.bandwidth, "graph_bp_both_strands": int(graph.bp),
                    "parallelism": "reads sharded, graph replicated, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": traffic, "kernel": "ga_extend_kernel<32>", "kernel_ms": round(k_ms, 3),
+                     "traffic": traffic, "kernel": "ga_extend_kernel<32,false>", "kernel_ms": round(k_ms, 3), "frac_of_measured_stream_copy": round(achieved / HBM_STREAM_GBS, 5),
                      "column_updates_per_launch": int(st["column_updates"]), "bytes_per_column_update": BYTES_PER_COLUMN_UPDATE},
         "detail": {"reads_failed": n_failed, "jobs": int(st["n_jobs"]), "jobs_retried_wide": int(st["jobs_retried"]), "slots": int(st["slots"]),
                    "scratch_GB": round(st["scratch_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "prepare_s": round(t_prep, 1), "collect_s": round(t_collect, 2), "end_to_end_Gbp_s_incl_collect": round(aligned_bp / (k_ms * 1e-3 + t_collect) / 1e9, 3),
