@@ -26,12 +26,6 @@ using namespace gaw;
 constexpr int W = 64;
 constexpr uint32_t kCutoff = 200000;         // GraphAlignerCommon.h:10
 constexpr int kSliceHdrWords = 12;          // nNodes, nCols, minScore, minSlot, minOffset, flags, logCorrect(2), logWrong(2), slice, reserved
-#ifndef GA_TWO_STAGE_SCAN
-#define GA_TWO_STAGE_SCAN 0
-#endif
-#ifndef GA_ABLATE
-#define GA_ABLATE 0          // timing experiments only (results are wrong when non-zero)
-#endif
 constexpr int kNbr = 4;                      // neighbours per band node cached in LDS
 
 template <int MAXN> struct Limits
@@ -763,27 +757,12 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				// ---- emit column c-1: vertical deltas against the row above (row j-1 holds T = before + 1) ----
 				vp = ballot(T == sh);                                            // delta +1
 				vn = ballot(Tp1 < sh);                                           // delta -1
-#if GA_ABLATE != 1
 				accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, c - 1);
 				accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), c - 1);
 				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, c - 1);
 				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), c - 1);
-#endif
-#if GA_TWO_STAGE_SCAN
-				// two scan steps settle the column unless a vertical run longer than three rows ends in it; that
-				// shows as a lane whose T exceeds the T of the row above (T must be non-increasing down the column)
-				const VI head = prefix_min_head(G);
-				T = vmin(head, bp1v);
-				sh = shr1v(T, bp1v);
-				if (ballot(T > sh))
-				{
-					T = vmin(prefix_min_tail(head), bp1v);
-					sh = shr1v(T, bp1v);
-				}
-#else
 				T = vmin(prefix_min(G), bp1v);
 				sh = shr1v(T, bp1v);
-#endif
 				Tp1 = T + 1;
 			}
 			vp = ballot(T == sh);

@@ -79,15 +79,6 @@ inline VU low_mask_through_lane() { VU r; for (int i = 0; i < LANES; i++) r.v[i]
 inline VI shr1(const VI& x, int fill) { VI r; r.v[0] = fill; for (int i = 1; i < LANES; i++) r.v[i] = x.v[i - 1]; return r; }
 // inclusive prefix minimum over lanes 0..i
 inline VI prefix_min(const VI& x) { VI r; int m = INF; for (int i = 0; i < LANES; i++) { m = x.v[i] < m ? x.v[i] : m; r.v[i] = m; } return r; }
-// the first two / the remaining four steps of the same scan: window minimum over lanes i-3..i, then the rest
-inline VI prefix_min_head(const VI& x) { VI r; for (int i = 0; i < LANES; i++) { int m = x.v[i]; for (int k = 1; k <= 3 && i - k >= (i & ~15); k++) m = x.v[i - k] < m ? x.v[i - k] : m; r.v[i] = m; } return r; }
-inline VI prefix_min_tail(const VI& x)
-{
-	// x is already a width-4 window minimum inside each row of 16 lanes; finish to a full inclusive prefix minimum
-	VI r; int m = INF;
-	for (int i = 0; i < LANES; i++) { m = x.v[i] < m ? x.v[i] : m; r.v[i] = m; }
-	return r;
-}
 inline uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < LANES; i++) if (c.v[i]) m |= 1ull << i; return m; }
 inline int read_lane(const VI& x, int lane) { return x.v[lane]; }
 inline VI write_lane(VI x, int value, int lane) { x.v[lane] = value; return x; }
@@ -149,24 +140,6 @@ GA_FN VI prefix_min(VI v)
 	const int ID = 0x7fffffff;
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x143, 0xc, 0xf, false));
-	return v;
-}
-// the scan split in two: most columns are settled by the first two steps (no vertical run longer
-// than three rows ends in them), which the caller detects from the deltas it computes anyway
-GA_FN VI prefix_min_head(VI v)
-{
-	const int ID = 0x7fffffff;
-	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x111, 0xf, 0xf, false));
-	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x112, 0xf, 0xf, false));
-	return v;
-}
-GA_FN VI prefix_min_tail(VI v)
-{
-	const int ID = 0x7fffffff;
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x114, 0xf, 0xf, false));
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x118, 0xf, 0xf, false));
 	v = vmin(v, __builtin_amdgcn_update_dpp(ID, v, 0x142, 0xa, 0xf, false));
