@@ -744,27 +744,34 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				Tp1 = T + 1;
 			}
 			// the two per-column scalars (T of the virtual row j-1, bit offset into rowCode2) are fetched one
-			// column ahead with a uniform ds_bpermute: they arrive in VGPRs without spending VALU cycles
-			VI bp1Next = lane_broadcast(beforeP1V, 1), offNext = lane_broadcast(offV, 1);
-			for (c = 1; c < n; c++)
-			{
-				// ---- column w0+c from the column to its left (calculateNode :1533-1546, getNextSlice :1349-1427) ----
-				const VI bp1v = bp1Next, offv = offNext;
-				bp1Next = lane_broadcast(beforeP1V, c + 1);
-				offNext = lane_broadcast(offV, c + 1);
+			// column ahead with a uniform ds_bpermute: they arrive in VGPRs without spending VALU cycles.  The loop
+			// is unrolled by two so that the fetched pair alternates between two register pairs instead of being copied.
+			auto column = [&](const VI& bp1v, const VI& offv, int col) {
+				// ---- column w0+col from the column to its left (calculateNode :1533-1546, getNextSlice :1349-1427) ----
 				const VI eq = bit_extract_v(rowCode2, offv);
 				const VI G = vmin(Tp1, sh - eq);
-				// ---- emit column c-1: vertical deltas against the row above (row j-1 holds T = before + 1) ----
+				// ---- emit column col-1: vertical deltas against the row above (row j-1 holds T = before + 1) ----
 				vp = ballot(T == sh);                                            // delta +1
 				vn = ballot(Tp1 < sh);                                           // delta -1
-				accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, c - 1);
-				accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), c - 1);
-				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, c - 1);
-				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), c - 1);
+				accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, col - 1);
+				accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), col - 1);
+				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, col - 1);
+				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), col - 1);
 				T = vmin(prefix_min(G), bp1v);
 				sh = shr1v(T, bp1v);
 				Tp1 = T + 1;
+			};
+			const int nU = wave_uniform(n);
+			VI bpA = lane_broadcast(beforeP1V, 1), offA = lane_broadcast(offV, 1);
+			for (c = 1; c + 1 < nU; c += 2)
+			{
+				const VI bpB = lane_broadcast(beforeP1V, c + 1), offB = lane_broadcast(offV, c + 1);
+				column(bpA, offA, c);
+				bpA = lane_broadcast(beforeP1V, c + 2);
+				offA = lane_broadcast(offV, c + 2);
+				column(bpB, offB, c + 1);
 			}
+			if (c < nU) column(bpA, offA, c);
 			vp = ballot(T == sh);
 			vn = ballot(Tp1 < sh);
 			accVpLo = write_lane(accVpLo, (int)(uint32_t)vp, n - 1);

@@ -94,6 +94,8 @@ inline VU load_lanes_u64(const uint64_t* p, int count) { VU r; for (int i = 0; i
 template <typename T> inline VI gather(const T* p, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)p[idx.v[i]]; return r; }
 inline VU gather64(const uint64_t* p, const VI& idx) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = p[idx.v[i]]; return r; }
 template <typename T> inline void scatter(T* p, const VI& idx, const VI& x, const VB& m) { for (int i = 0; i < LANES; i++) if (m.v[i]) p[idx.v[i]] = (T)x.v[i]; }
+// a value every lane holds identically, handed to the scalar unit
+inline int wave_uniform(int x) { return x; }
 inline void wave_sync() {}
 inline void wave_order() {}
 inline uint64_t stamp() { return 0; }
@@ -167,6 +169,7 @@ template <typename T> GA_FN VI gather(const T* p, VI idx) { return (int)p[idx]; 
 GA_FN VU gather64(const uint64_t* p, VI idx) { return p[idx]; }
 template <typename T> GA_FN void scatter(T* p, VI idx, VI x, VB m) { if (m) p[idx] = (T)x; }
 // one wave per workgroup: orders this wave's LDS / global traffic (s_waitcnt + s_barrier)
+GA_FN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 GA_FN void wave_sync() { __syncthreads(); }
 // compiler-only ordering point: a single wave executes its LDS traffic in order, no wait is needed
 GA_FN void wave_order() { __builtin_amdgcn_wave_barrier(); }
