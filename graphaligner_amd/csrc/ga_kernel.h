@@ -1771,7 +1771,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		{
 			if (row == 0xffffffffu) break;                                       // reached the row before the first one
 			if (len + LANES >= L.trace_cap) { status = GA_CAP_TRACE; break; }
-			const int r = (int)(row - sIdx * W);
+			int r = (int)(row - sIdx * W);
 			if (rowvSlice != sIdx) { rowv = load_lanes(rows + sIdx * W, W, 0); rowvSlice = sIdx; }
 			// ---- make the current window cover this column (and its left neighbour when there is one) ----
 			bool covers = cw.valid && cw.slice == sIdx && cw.node == node && (int)offset >= cw.lo && (int)offset < cw.lo + cw.n && !((int)offset == cw.lo && offset > 0);
@@ -1793,10 +1793,10 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			}
 			if (winRecNode != node) { winRec = g_record(g, node); winRecNode = node; }
 			if (!cw.present) { status = GA_ASSERTION; break; }                   // assert(slice.scores.hasNode(nodeIndex)) (:498)
-			const int rel = (int)offset - cw.lo;
-			const uint64_t maskR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull;
-			const VI valR = cw.before + vpopc(maskR & cw.vp) - vpopc(maskR & cw.vn);
-			const int here = read_lane(valR, rel);
+			int rel = (int)offset - cw.lo;
+			uint64_t maskR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull;
+			VI valR = cw.before + vpopc(maskR & cw.vp) - vpopc(maskR & cw.vn);
+			int here = read_lane(valR, rel);
 			if (row == 0 && node == job.seed_node && (here == 0 || here == 1)) { row = 0xffffffffu; continue; }   // free start (:500)
 			// ---- a run of diagonal steps inside the window, all at once ----
 			// Lane L looks at the diagonal cell (column L, row L + r - rel).  A step from column L+1
@@ -1805,9 +1805,10 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			if (rel >= 1 && r >= 1)
 			{
 				const VI rho = lane + (r - rel);
-				const VU mA = mask_low_bits(rho + 1), mB = mask_low_bits(rho + 2);
+				const VU mA = mask_low_bits(rho + 1);
 				const VI A = cw.before + vpopc(cw.vp & mA) - vpopc(cw.vn & mA);
-				const VI B = cw.before + vpopc(cw.vp & mB) - vpopc(cw.vn & mB);
+				// one row further down: add that row's vertical delta
+				const VI B = A + bit64_at(cw.vp, rho + 1) - bit64_at(cw.vn, rho + 1);
 				const VI mOwn = (lane_gather(rowv, rho) >> winBases) & 1;
 				const VI hereSrc = shl1(A, 0), mSrc = shl1(mOwn, 0);
 				const uint64_t cond = ballot(B > hereSrc - 1) & ballot(A == hereSrc - 1 + mSrc) & ballot((lane < rel) && (rho > -1));
@@ -1821,7 +1822,16 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 					len += (uint32_t)run;
 					offset -= (uint32_t)run;
 					row -= (uint32_t)run;
-					continue;
+					// the run ended because the next step is not a plain diagonal one: take that step right away from the new
+					// cell (same window, same slice) unless the window has to move first
+					rel -= run;
+					r -= run;
+					if (rel == 0 && offset > 0) continue;
+					maskR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull;
+					valR = cw.before + vpopc(maskR & cw.vp) - vpopc(maskR & cw.vn);
+					here = read_lane(valR, rel);
+					if (row == 0 && node == job.seed_node && (here == 0 || here == 1)) { row = 0xffffffffu; continue; }
+					if (len + LANES >= L.trace_cap) { status = GA_CAP_TRACE; break; }
 				}
 			}
 			const int rowCode = read_lane(rowv, r);

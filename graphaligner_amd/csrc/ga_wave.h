@@ -60,6 +60,8 @@ inline VI lane_broadcast(const VI& x, int lane) { VI r; for (int i = 0; i < LANE
 inline VI shr1v(const VI& x, const VI& fill) { VI r; r.v[0] = fill.v[0]; for (int i = 1; i < LANES; i++) r.v[i] = x.v[i - 1]; return r; }
 inline VI bit_extract_v(const VI& x, const VI& bit) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (x.v[i] >> bit.v[i]) & 1; return r; }
 inline VI lane_gather(const VI& x, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = x.v[idx.v[i] & 63]; return r; }
+// bit `pos` of a per-lane 64-bit word (0 when pos is outside 0..63)
+inline VI bit64_at(const VU& w, const VI& pos) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (pos.v[i] < 0 || pos.v[i] > 63) ? 0 : (int)((w.v[i] >> pos.v[i]) & 1); return r; }
 // per-lane word with the low `nbits` bits set (nbits <= 0 -> 0, >= 64 -> all)
 inline VU mask_low_bits(const VI& nbits) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = nbits.v[i] <= 0 ? 0ull : nbits.v[i] >= 64 ? ~0ull : ((1ull << nbits.v[i]) - 1); return r; }
 inline VI lane_iota() { VI r; for (int i = 0; i < LANES; i++) r.v[i] = i; return r; }
@@ -123,6 +125,7 @@ GA_FN VI lane_broadcast(VI x, int lane) { return __builtin_amdgcn_ds_bpermute((l
 GA_FN VI shr1v(VI x, VI fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
 GA_FN VI bit_extract_v(VI x, VI bit) { return (int)__builtin_amdgcn_ubfe((unsigned)x, (unsigned)bit, 1u); }
 GA_FN VU mask_low_bits(VI nbits) { return nbits <= 0 ? 0ull : nbits >= 64 ? ~0ull : ((1ull << nbits) - 1); }
+GA_FN VI bit64_at(VU w, VI pos) { return (pos < 0 || pos > 63) ? 0 : (int)((w >> pos) & 1); }
 GA_FN VI lane_iota() { return (int)threadIdx.x; }
 GA_FN VI vmin(VI a, VI b) { return a < b ? a : b; }
 GA_FN VI select(VB c, VI a, VI b) { return c ? a : b; }
