@@ -749,7 +749,8 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			auto column = [&](const VI& bp1v, const VI& offv, int col) {
 				// ---- column w0+col from the column to its left (calculateNode :1533-1546, getNextSlice :1349-1427) ----
 				const VI eq = bit_extract_v(rowCode2, offv);
-				const VI G = vmin(Tp1, sh - eq);
+				// the cap before' + 1 is the same for every row, so it can go inside the scan: one v_min3 feeds six fused v_min_dpp
+				const VI G = vmin(vmin(Tp1, sh - eq), bp1v);
 				// ---- emit column col-1: vertical deltas against the row above (row j-1 holds T = before + 1) ----
 				vp = ballot(T == sh);                                            // delta +1
 				vn = ballot(Tp1 < sh);                                           // delta -1
@@ -757,7 +758,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 				accVpHi = write_lane(accVpHi, (int)(uint32_t)(vp >> 32), col - 1);
 				accVnLo = write_lane(accVnLo, (int)(uint32_t)vn, col - 1);
 				accVnHi = write_lane(accVnHi, (int)(uint32_t)(vn >> 32), col - 1);
-				T = vmin(prefix_min(G), bp1v);
+				T = prefix_min(G);
 				sh = shr1v(T, bp1v);
 				Tp1 = T + 1;
 			};
