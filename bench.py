@@ -66,7 +66,14 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     import __graft_entry__ as entry
-    entry.build_product()
+    # one rank builds (a fresh snapshot can make the in-tree library look stale); the others wait and only load it
+    if world > 1:
+        if rank == 0:
+            entry.build_product()
+        dist.barrier()
+        os.environ["GA_SKIP_BUILD"] = "1"
+    else:
+        entry.build_product()
     from graphaligner_amd import binding, synth
 
     t0 = time.time()
