@@ -288,6 +288,8 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	if (hipSetDevice(device) != hipSuccess) { *status = GA_E_NO_DEVICE; return nullptr; }
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { *status = GA_E_NO_DEVICE; return nullptr; }
+	// node records are addressed with 32-bit lane arithmetic (node << 4 words): up to 2^27 directed nodes
+	if (flat.node_start.size() - 1 >= (1ull << 27)) { *status = GA_E_INVALID; return nullptr; }
 	DevGraph* g = new DevGraph();
 	g->device = device;
 	g->cus = prop.multiProcessorCount;
