@@ -202,11 +202,11 @@ struct DevBatch : GaBackendBatch
 		// ---- what the lean variant could not finish climbs a ladder: 64 band nodes in LDS; then the general variants, which
 		// also carry the paths for bands with cycles and for ramp redos; last 256 band nodes with large buffers ----
 		st.jobs_retried = 0;
-		int rc = retryPass<64, false>(8192, 3 * 64 + 5 * 2048, 3, 12, false);
+		int rc = retryPass<64, false>(8192, 3 * 64 + 5 * 2048, 3, 12, true, false);
 		if (rc) return rc;
-		rc = retryPass<64, true>(8192, 3 * 64 + 5 * 4096, 4, 8, true);
+		rc = retryPass<64, true>(8192, 3 * 64 + 5 * 4096, 4, 8, false, true);      // only what needs the extra paths: capacity misses go straight on
 		if (rc) return rc;
-		rc = retryPass<256, true>(65536, 3 * 256 + 5 * 8192, 6, 4, true);
+		rc = retryPass<256, true>(65536, 3 * 256 + 5 * 8192, 6, 4, true, true);
 		return rc;
 	}
 
@@ -214,10 +214,10 @@ struct DevBatch : GaBackendBatch
 	// bands with cycles and ramp redos: only the general variants carry those paths
 	static bool needsGeneral(int s) { return s == GA_UNSUPPORTED_CYCLE || s == GA_UNSUPPORTED_RAMP; }
 
-	template <int MAXN, bool GENERAL> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry, bool general)
+	template <int MAXN, bool GENERAL> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry, bool takeCapacity, bool takeGeneral)
 	{
 		std::vector<uint32_t> again;
-		for (uint32_t i = 0; i < outs.size(); i++) if (isCapacity(outs[i].status) || (general && needsGeneral(outs[i].status))) again.push_back(i);
+		for (uint32_t i = 0; i < outs.size(); i++) if ((takeCapacity && isCapacity(outs[i].status)) || (takeGeneral && needsGeneral(outs[i].status))) again.push_back(i);
 		if (again.empty()) return 0;
 		st.jobs_retried += again.size();
 		GaLaunch R = L;
