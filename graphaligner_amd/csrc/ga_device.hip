@@ -166,13 +166,8 @@ struct DevBatch : GaBackendBatch
 		uint64_t want = (uint64_t)g->cus * wavesPerCu;
 		uint64_t fit = (uint64_t)(freeB * 0.8) / std::max<uint64_t>(lay.bytes, 1);
 		slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(want, fit), std::max<size_t>(jobs.size(), 1)));
-		// every slot takes ceil(jobs / slots) jobs one after the other; with that many rounds fixed, use
-		// just enough slots to fill them evenly (fewer co-resident waves = faster rounds, same round count)
-		if (!jobs.empty())
-		{
-			uint64_t rounds = (jobs.size() + slots - 1) / slots;
-			slots = (uint32_t)((jobs.size() + rounds - 1) / rounds);
-		}
+		// (jobs are pulled from a device queue, so the slots need no balancing by hand; a few more workgroups than fit at once
+		// start as the first ones drain the queue and even out the tail)
 		if (alloc(&L.scratch, (size_t)slots * lay.bytes)) return GA_E_DEVICE;
 		st.slots = slots;
 		st.waves_per_cu = wavesPerCu;
