@@ -99,6 +99,7 @@ struct DevBatch : GaBackendBatch
 	uint32_t slots = 0, wavesPerCu = 0;
 	bool narrow = true;         // first pass with the 32-node variant (more waves per CU); misses go to the 256-node variant
 	std::vector<GaJobOut> outs;
+	std::vector<uint32_t> orderHost;   // job order of the main launch (longest first) when lengths differ
 	GaRunStats st;
 	// retry pass (wide variant), built lazily
 	uint8_t* retryScratch = nullptr;
@@ -145,6 +146,19 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GaJob), hipMemcpyHostToDevice, stream));
 		L.rows = dRows;
 		L.jobs = dJobs;
+		// the device queue hands jobs out longest first: the short ones fill the tail of the launch
+		bool uniform = true;
+		for (auto& j : jobs) if (j.n_rows != jobs[0].n_rows) { uniform = false; break; }
+		if (!uniform)
+		{
+			orderHost.resize(jobs.size());
+			for (uint32_t i = 0; i < jobs.size(); i++) orderHost[i] = i;
+			std::stable_sort(orderHost.begin(), orderHost.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n_rows > jobs[b].n_rows; });
+			uint32_t* dOrder;
+			if (alloc(&dOrder, orderHost.size())) return GA_E_DEVICE;
+			HIP_OK(hipMemcpyAsync(dOrder, orderHost.data(), orderHost.size() * 4, hipMemcpyHostToDevice, stream));
+			L.job_list = dOrder;
+		}
 		if (alloc(&L.outs, jobs.size())) return GA_E_DEVICE;
 		if (alloc(&L.next_job, 4)) return GA_E_DEVICE;
 		if (alloc(&L.trace_top, 2)) return GA_E_DEVICE;
