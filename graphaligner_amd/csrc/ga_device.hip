@@ -207,6 +207,7 @@ struct DevBatch : GaBackendBatch
 		float ms = 0;
 		HIP_OK(hipEventElapsedTime(&ms, evStart, evStop));
 		st.kernel_ms = ms;
+		if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: main pass: %zu jobs on %u slots, %.2f ms\n", jobs.size(), slots, ms);
 		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
 		// ---- what the lean variant could not finish climbs a ladder: 64 band nodes in LDS; then the general variants, which
 		// also carry the paths for bands with cycles and for ramp redos; last 256 band nodes with large buffers ----
@@ -269,6 +270,7 @@ struct DevBatch : GaBackendBatch
 		float ms2 = 0;
 		HIP_OK(hipEventElapsedTime(&ms2, a, b));
 		st.kernel_ms += ms2;
+		if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: retry pass <%d,%d>: %zu jobs on %u slots, %.2f ms\n", MAXN, (int)GENERAL, again.size(), rslots, ms2);
 		hipEventDestroy(a);
 		hipEventDestroy(b);
 		return 0;
@@ -303,7 +305,7 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	g->device = device;
 	g->cus = prop.multiProcessorCount;
 	g->g.n_nodes = (uint32_t)(flat.node_start.size() - 1);
-	g->g.reserved = 0;
+	g->g.reserved = getenv("GA_DIAG_NO_TRACEBACK") ? 1u : 0u;     // diagnostic: counters of the fill phases alone (results are then incomplete)
 	int bad = 0;
 	bad |= g->put(flat.node_start, &g->g.node_start);
 	bad |= g->put(flat.seq2, &g->g.seq2);

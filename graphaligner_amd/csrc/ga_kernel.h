@@ -1695,7 +1695,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	{
 		if (numSlices < 4) status = GA_ASSERTION;                                // assert(slice.samplingFrequency > 1) (:906)
 	}
-	if (status == GA_OK && kept > 0)
+	if (status == GA_OK && kept > 0 && !(g.reserved & 1u))                      // (bit 0 of `reserved`: instruction-count experiments run without the traceback)
 	{
 		uint8_t* tr = slot.trace;
 		const int big = (int)job.n_rows;                                         // getValueOrMax default = sequence.size()
