@@ -29,6 +29,26 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_STREAM_GBS = 5318.6             # what a streaming copy reaches on this pool (profiles/r1_hbm_stream.txt, tools/hbm_stream.hip)
 
 
+def _usable_cores():
+    """threads this process can really run at once: the affinity mask, capped by a cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +187,7 @@ def main():
     if args.cpu_sample > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding as ob
-        cores = os.cpu_count() or 1
+        cores = _usable_cores()
         n = min(args.cpu_sample, len(reads))
         og = ob.OracleGraph(g.nodes, g.edges)
         b = og.bench(reads[:n], seeds[:n], args.bandwidth, 0, cores)
