@@ -815,8 +815,8 @@ const char* ga_status_string(int s)
 		case GA_S_UNSUPPORTED_BAND: return "band >= 200000 bp (sparse method not built)";
 		case GA_S_BAD_SEED: return "seed node not in graph";
 		case GA_S_CAPACITY: return "device buffer capacity";
-		case GA_S_UNSUPPORTED_CYCLE: return "cyclic band (not built on device)";
-		case GA_S_UNSUPPORTED_RAMP: return "ramp redo (not built on device)";
+		case GA_S_UNSUPPORTED_CYCLE: return "cyclic band left unresolved by the kernel ladder";
+		case GA_S_UNSUPPORTED_RAMP: return "ramp redo left unresolved by the kernel ladder";
 		case GA_E_INVALID: return "invalid argument";
 		case GA_E_NO_DEVICE: return "no gfx950 device / graph not uploaded";
 		case GA_E_DEVICE: return "device error";

@@ -35,8 +35,8 @@ typedef enum ga_status {
 	GA_S_UNSUPPORTED_BAND = 2,  /* band >= 200000 bp: reference uses its sparse method (GraphAligner.h:2483); not built */
 	GA_S_BAD_SEED = 3,          /* seed node id unknown: std::out_of_range in the reference (GraphAligner.h:423) */
 	GA_S_CAPACITY = 10,         /* device buffers too small even after the automatic retry */
-	GA_S_UNSUPPORTED_CYCLE = 20,/* band subgraph has a cycle (GraphAligner.h:2362-2397 iterative confirmation); not built */
-	GA_S_UNSUPPORTED_RAMP = 21, /* ramp redo (GraphAligner.h:2648-2719) would be taken; not built */
+	GA_S_UNSUPPORTED_CYCLE = 20,/* internal: band subgraph has a cycle (GraphAligner.h:2362-2397); resolved by the general kernel variants, not returned */
+	GA_S_UNSUPPORTED_RAMP = 21, /* internal: ramp redo (GraphAligner.h:2648-2719) taken; resolved by the general kernel variants, not returned */
 	/* call-level errors */
 	GA_E_INVALID = 100,
 	GA_E_NO_DEVICE = 101,
