@@ -101,6 +101,29 @@ class OracleGraph:
                 raise ValueError("add edge failed: %s" % STATUS.get(st, st))
         L.gao_graph_finalize(self.h)
 
+    @classmethod
+    def from_gfa_segments(cls, segments, links, overlap):
+        """the GFA loader's conversion (BigraphToDigraph.cpp:58-104, 137-189): forward node = the segment minus its last
+        `overlap` bases, backward node = the reverse complement of the WHOLE segment minus ITS last `overlap` bases;
+        links: (from, from_is_minus, to, to_is_minus)"""
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        L = lib()
+        self = cls.__new__(cls)
+        self.h = L.gao_graph_new()
+        L.gao_graph_set_overlap(self.h, overlap)
+        for nid, seq in segments:
+            rc = "".join(comp[c] for c in reversed(seq))
+            for did, s, rev in ((2 * nid, seq[:len(seq) - overlap], 0), (2 * nid + 1, rc[:len(seq) - overlap], 1)):
+                st = L.gao_graph_add_node(self.h, int(did), s.encode(), rev)
+                if st:
+                    raise ValueError("add node failed: %s" % STATUS.get(st, st))
+        for f, fs, t, te in links:
+            st = L.gao_graph_add_bigraph_edge(self.h, int(f), int(fs), int(t), int(te))
+            if st:
+                raise ValueError("add edge failed: %s" % STATUS.get(st, st))
+        L.gao_graph_finalize(self.h)
+        return self
+
     def __del__(self):
         try:
             lib().gao_graph_free(self.h)

@@ -98,6 +98,47 @@ def case_ramp_redo(node_len, bw, ramp, err, lib_path=None):
     assert n_ok >= 12, n_ok
 
 
+def case_gfa_overlap(lib_path=None):
+    """de Bruijn-style GFA: consecutive segments share k bases and the L lines say `kM`.  The loader trims k bases off
+    every node (the backward node is cut from the reverse complement of the WHOLE segment, BigraphToDigraph.cpp:58-68) and
+    the engine extends the backward part of a read k bases past the seed and keeps k bases of the forward part out of the
+    trace (GraphAligner.h:2991, 3054-3095)."""
+    import oracle_binding as ob
+    rng = np.random.default_rng(3)
+    for k, node_len in ((15, 60), (31, 80)):
+        gs = synth.random_genome(20000, 70 + k).tobytes().decode()
+        step = node_len - k
+        segs = []
+        i, nid = 0, 1
+        while i + node_len <= len(gs):
+            segs.append((nid, gs[i:i + node_len]))
+            i += step
+            nid += 1
+        links = [(segs[a][0], False, segs[a + 1][0], False) for a in range(len(segs) - 1)]
+        gfa = "H\tVN:Z:1.0\n" + "".join("S\t%d\t%s\n" % x for x in segs) + "".join("L\t%d\t+\t%d\t+\t%dM\n" % (f, t, k) for f, _, t, _ in links)
+        reads, seeds = [], []
+        noisy = lambda a, b: synth.add_errors(np.frombuffer(gs[a:b].encode(), dtype=np.uint8), 0.03, 0.03, 0.03, rng).tobytes().decode()
+        for t in range(10):
+            a = int(rng.integers(5, len(segs) - 40))
+            if t % 2 == 0:
+                reads.append(noisy(a * step, a * step + 1200))
+                seeds.append((segs[a][0], 0, False))
+            else:
+                b = a + 10
+                pre = noisy(a * step, b * step)
+                reads.append(pre + noisy(b * step, b * step + 700))
+                seeds.append((segs[b][0], len(pre), False))
+        g = binding.Graph(gfa=gfa, lib_path=lib_path)
+        devs = g.align(reads, seeds, 35, 0, flags=binding.GA_F_TRACE)
+        og = ob.OracleGraph.from_gfa_segments(segs, links, k)
+        n_ok = 0
+        for i, (r, sd) in enumerate(zip(reads, seeds)):
+            o = og.align(r, [sd], 35)
+            pc.compare_read(devs[i], o, "overlap %d read %d" % (k, i))
+            n_ok += int(o["status"] == 0 and not o["failed"])
+        assert n_ok >= 8, n_ok
+
+
 def case_short_and_edge_reads(lib_path=None):
     """directions shorter than 193 bp hit assert(samplingFrequency > 1) in the reference
     (GraphAligner.h:906); seeds at the last base align backwards only (:3006)"""

@@ -32,6 +32,10 @@ def test_ramp_redo(lib, node_len, bw, ramp, err):
     cases.case_ramp_redo(node_len, bw, ramp, err, lib)
 
 
+def test_gfa_overlap(lib):
+    cases.case_gfa_overlap(lib)
+
+
 def test_short_and_edge_reads(lib):
     cases.case_short_and_edge_reads(lib)
 

@@ -34,6 +34,10 @@ def test_ramp_redo(node_len, bw, ramp, err):
     cases.case_ramp_redo(node_len, bw, ramp, err)
 
 
+def test_gfa_overlap():
+    cases.case_gfa_overlap()
+
+
 def test_short_and_edge_reads():
     cases.case_short_and_edge_reads()
 
