@@ -139,6 +139,40 @@ def case_gfa_overlap(lib_path=None):
         assert n_ok >= 8, n_ok
 
 
+def case_inversion_edges(lib_path=None):
+    """bidirected edges that enter a node at its end or leave it from its start (from_start / to_end of vg.Edge,
+    BigraphToDigraph.cpp:32-56): every seventh segment is stored reverse-complemented, so reads run through nodes in both
+    orientations; seeds on inverted nodes carry reverse = true, and some reads come from the other strand."""
+    rng = np.random.default_rng(5)
+    gs = synth.random_genome(30000, 99).tobytes().decode()
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda x: "".join(comp[c] for c in reversed(x))
+    seg = 40
+    pieces = [gs[i:i + seg] for i in range(0, len(gs) - seg, seg)]
+    inverted = [i % 7 == 3 for i in range(len(pieces))]
+    nodes = [(i + 1, rc(p) if inverted[i] else p) for i, p in enumerate(pieces)]
+    edges = [(i + 1, inverted[i], i + 2, inverted[i + 1]) for i in range(len(pieces) - 1)]
+    noisy = lambda a, b: synth.add_errors(np.frombuffer(gs[a:b].encode(), dtype=np.uint8), 0.03, 0.03, 0.03, rng).tobytes().decode()
+    reads, seeds = [], []
+    for t in range(16):
+        a = int(rng.integers(3, len(pieces) - 40))
+        if t % 2 == 0:
+            reads.append(noisy(a * seg, a * seg + 1200))
+            seeds.append((a + 1, 0, inverted[a]))
+        else:
+            b = a + 12
+            pre = noisy(a * seg, b * seg)
+            reads.append(pre + noisy(b * seg, b * seg + 700))
+            seeds.append((b + 1, len(pre), inverted[b]))
+        if t % 4 == 3:
+            n, pos, _ = seeds[-1]
+            reads[-1] = rc(reads[-1])
+            seeds[-1] = (n - 1, len(reads[-1]) - pos, not inverted[n - 2])      # the node before, read from the other strand
+    devs, oras = pc.check_parity(nodes, edges, reads, seeds, 35, lib_path=lib_path, ctx="inversions")
+    assert sum(1 for d in devs if d["status"] == 0 and not d["failed"]) >= 14
+    assert {m[1] for d in devs for m in d["mappings"]} == {0, 1}
+
+
 def case_short_and_edge_reads(lib_path=None):
     """directions shorter than 193 bp hit assert(samplingFrequency > 1) in the reference
     (GraphAligner.h:906); seeds at the last base align backwards only (:3006)"""

@@ -36,6 +36,10 @@ def test_gfa_overlap(lib):
     cases.case_gfa_overlap(lib)
 
 
+def test_inversion_edges(lib):
+    cases.case_inversion_edges(lib)
+
+
 def test_short_and_edge_reads(lib):
     cases.case_short_and_edge_reads(lib)
 

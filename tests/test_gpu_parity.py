@@ -38,6 +38,10 @@ def test_gfa_overlap():
     cases.case_gfa_overlap()
 
 
+def test_inversion_edges():
+    cases.case_inversion_edges()
+
+
 def test_short_and_edge_reads():
     cases.case_short_and_edge_reads()
 
