@@ -183,6 +183,13 @@ def case_short_and_edge_reads(lib_path=None):
         cases_r += [r[:100], r[:192], r[:193], r[:256], r, r, r]
         cases_s += [s, s, s, s, (s[0], 1, s[2]), (s[0], len(r) - 1, s[2]), (s[0], 400, s[2])]
     pc.check_parity(g.nodes, g.edges, cases_r, cases_s, 35, lib_path=lib_path, ctx="edge")
+    # degenerate inputs: empty read and seed position past the end (assert(matchSequencePosition < sequence.size()), :2972),
+    # a one-base read, a read of N only (matches everything: score 0), a seed on the last base of the other strand
+    n0 = g.nodes[3][0]
+    tiny_r = ["", "A", "ACGT" * 70, "N" * 400, "ACGT" * 70]
+    tiny_s = [(n0, 0, False), (n0, 0, False), (n0, 280, False), (n0, 0, False), (n0, 279, True)]
+    devs, _ = pc.check_parity(g.nodes, g.edges, tiny_r, tiny_s, 35, lib_path=lib_path, ctx="degenerate")
+    assert [d["status"] for d in devs] == [1, 0, 1, 0, 0] and devs[3]["score"] == 0 and not devs[3]["failed"]
 
 
 def case_iupac_n_and_invalid_characters(lib_path=None):
