@@ -46,3 +46,52 @@ def test_no_cpu_fallback_without_device():
 def test_product_library_does_not_contain_the_oracle_or_the_emulation():
     data = open(LIB, "rb").read()
     assert b"gao_align" not in data and b"ga_emul_" not in data
+
+
+def test_digraph_level_calls_and_one_shot_entry_point():
+    """the calls the reference-side binding of INTEGRATION.md uses: ga_graph_add_node / ga_graph_add_edge with digraph ids
+    (AlignmentGraph::AddNode / AddEdgeNodeId) and the one-shot ga_align_batch, against the bigraph calls + batch interface.
+    Runs the device program through the host emulation (this container has no GPU)."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from graphaligner_amd import binding, synth
+    import parity_common as pc
+    lib = pc.emul_lib_path()
+    L = binding.load(lib)
+    g = synth.bubble_graph(15000, node_len=32, seed=31)
+    reads, seeds = synth.simulate_reads(g, 6, 900, seed=12, mid_seed=True)
+    ref = binding.Graph(g.nodes, g.edges, lib_path=lib).align(reads, seeds, 35)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    h = L.ga_graph_create()
+    for nid, seq in g.nodes:
+        rc = "".join(comp[c] for c in reversed(seq))
+        assert L.ga_graph_add_node(h, 2 * nid, seq.encode(), len(seq), 0) == 0
+        assert L.ga_graph_add_node(h, 2 * nid + 1, rc.encode(), len(rc), 1) == 0
+    for f, fs, t, te in g.edges:
+        # BigraphToDigraph.cpp:32-56: right end of `from` -> right end of `to`, and the mirrored edge
+        f_left, f_right = (2 * f, 2 * f + 1) if fs else (2 * f + 1, 2 * f)
+        t_left, t_right = (2 * t, 2 * t + 1) if te else (2 * t + 1, 2 * t)
+        assert L.ga_graph_add_edge(h, f_right, t_right) == 0
+        assert L.ga_graph_add_edge(h, t_left, f_left) == 0
+    assert L.ga_graph_finalize(h, 0) == 0
+    assert L.ga_graph_upload(h, 0) == 0
+    n = len(reads)
+    keep = [r.encode() for r in reads]
+    arr = (binding.GaRead * n)()
+    for i in range(n):
+        arr[i].name = b"r%d" % i
+        arr[i].sequence = keep[i]
+        arr[i].length = len(keep[i])
+    sarr = (binding.GaSeed * n)()
+    offs = (C.c_size_t * (n + 1))(*range(n + 1))
+    for i, (node, pos, rev) in enumerate(seeds):
+        sarr[i].node_id, sarr[i].read_pos, sarr[i].reverse = int(node), int(pos), int(bool(rev))
+    out = C.POINTER(binding.GaResults)()
+    assert L.ga_align_batch(h, arr, n, sarr, offs, 35, 0, 0, C.byref(out)) == 0
+    got = binding._unpack(out.contents)
+    L.ga_results_free(out)
+    L.ga_graph_destroy(h)
+    for a, b in zip(ref, got):
+        assert a["status"] == b["status"] and a["score"] == b["score"] and a["mappings"] == b["mappings"]
+    assert sum(1 for a in got if a["status"] == 0 and not a["failed"]) >= 5
