@@ -180,7 +180,8 @@ def main():
                      "column_updates_per_launch": int(st["column_updates"]), "bytes_per_column_update": BYTES_PER_COLUMN_UPDATE},
         "detail": {"reads_failed": n_failed, "jobs": int(st["n_jobs"]), "jobs_retried_wide": int(st["jobs_retried"]), "slots": int(st["slots"]),
                    "scratch_GB": round(st["scratch_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "prepare_s": round(t_prep, 1), "collect_s": round(t_collect, 2), "end_to_end_Gbp_s_incl_collect": round(aligned_bp / (k_ms * 1e-3 + t_collect) / 1e9, 3),
-                   "kernel_only_Gbp_s": round(aligned_bp / (k_ms * 1e-3) / 1e9, 4)},
+                   "kernel_only_Gbp_s": round(aligned_bp / (k_ms * 1e-3) / 1e9, 4),
+                   "G_column_updates_per_s": round(st["column_updates"] / (k_ms * 1e-3) / 1e9, 3), "GCUPS": round(64 * st["column_updates"] / (k_ms * 1e-3) / 1e9, 1)},
     }
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm), all host cores, bounded sample ----
