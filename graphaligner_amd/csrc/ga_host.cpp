@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <memory>
 #include <cstring>
 #include <limits>
 #include <sstream>
@@ -220,6 +222,11 @@ struct ResultsOwner
 	std::vector<ga_mapping_t> mappings;
 	std::vector<char> edits;
 	std::vector<ga_trace_item_t> trace;
+	// the stitched arrays of a whole batch: allocated without being cleared first (hundreds of MB)
+	std::unique_ptr<ga_read_result_t[]> allReads;
+	std::unique_ptr<ga_mapping_t[]> allMappings;
+	std::unique_ptr<char[]> allEdits;
+	std::unique_ptr<ga_trace_item_t[]> allTrace;
 };
 
 int mapDeviceStatus(int s)
@@ -600,8 +607,10 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	const ga_graph& g = *b->g;
 	std::vector<GaJobOut> outs;
 	std::vector<uint8_t> moves;
+	const auto t0 = std::chrono::steady_clock::now();
 	int s = b->dev->fetch(outs, moves);
 	if (s) return s;
+	const auto t1 = std::chrono::steady_clock::now();
 	b->columnUpdates = 0;
 	b->slicesRun = 0;
 	for (const GaJobOut& o : outs) { b->columnUpdates += o.n_columns; b->slicesRun += o.n_run; }
@@ -764,25 +773,60 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		}
 		for (auto& th : pool) th.join();
 	}
-	R->reads.clear();
-	for (ResultsOwner& part : parts)
+	const auto t2 = std::chrono::steady_clock::now();
+	// stitch the per-thread arrays: sizes first, then every part copies itself into place (rebased offsets) on its own thread
 	{
-		const uint64_t mapBase = R->mappings.size(), editBase = R->edits.size(), traceBase = R->trace.size();
-		for (ga_read_result_t rr : part.reads)
+		std::vector<uint64_t> readBase(nThreads + 1, 0), mapBase(nThreads + 1, 0), editBase(nThreads + 1, 0), traceBase(nThreads + 1, 0);
+		for (size_t t = 0; t < nThreads; t++)
 		{
-			rr.first_mapping += mapBase;
-			rr.first_trace += traceBase;
-			R->reads.push_back(rr);
+			readBase[t + 1] = readBase[t] + parts[t].reads.size();
+			mapBase[t + 1] = mapBase[t] + parts[t].mappings.size();
+			editBase[t + 1] = editBase[t] + parts[t].edits.size();
+			traceBase[t + 1] = traceBase[t] + parts[t].trace.size();
 		}
-		for (ga_mapping_t m : part.mappings) { m.edit_seq_off += editBase; R->mappings.push_back(m); }
-		R->edits.insert(R->edits.end(), part.edits.begin(), part.edits.end());
-		R->trace.insert(R->trace.end(), part.trace.begin(), part.trace.end());
+		R->allReads.reset(new ga_read_result_t[readBase[nThreads] + 1]);
+		R->allMappings.reset(new ga_mapping_t[mapBase[nThreads] + 1]);
+		R->allEdits.reset(new char[editBase[nThreads] + 1]);
+		R->allTrace.reset(new ga_trace_item_t[traceBase[nThreads] + 1]);
+		ga_read_result_t* const allReads = R->allReads.get();
+		ga_mapping_t* const allMappings = R->allMappings.get();
+		char* const allEdits = R->allEdits.get();
+		ga_trace_item_t* const allTrace = R->allTrace.get();
+		R->pub.n_reads = readBase[nThreads]; R->pub.reads = allReads;
+		R->pub.n_mappings = mapBase[nThreads]; R->pub.mappings = allMappings;
+		R->pub.n_edit_bytes = editBase[nThreads]; R->pub.edit_bytes = allEdits;
+		R->pub.n_trace = traceBase[nThreads]; R->pub.trace = allTrace;
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < nThreads; t++)
+			pool.emplace_back([&, t]() {
+				ResultsOwner& part = parts[t];
+				for (size_t i = 0; i < part.reads.size(); i++)
+				{
+					ga_read_result_t rr = part.reads[i];
+					rr.first_mapping += mapBase[t];
+					rr.first_trace += traceBase[t];
+					allReads[readBase[t] + i] = rr;
+				}
+				for (size_t i = 0; i < part.mappings.size(); i++)
+				{
+					ga_mapping_t m = part.mappings[i];
+					m.edit_seq_off += editBase[t];
+					allMappings[mapBase[t] + i] = m;
+				}
+				if (!part.edits.empty()) memcpy(allEdits + editBase[t], part.edits.data(), part.edits.size() * sizeof(part.edits[0]));
+				if (!part.trace.empty()) memcpy(allTrace + traceBase[t], part.trace.data(), part.trace.size() * sizeof(part.trace[0]));
+
+				std::vector<ga_mapping_t>().swap(part.mappings);
+			});
+		for (auto& th : pool) th.join();
 	}
-	R->pub.n_reads = R->reads.size(); R->pub.reads = R->reads.data();
-	R->pub.n_mappings = R->mappings.size(); R->pub.mappings = R->mappings.data();
-	R->pub.n_edit_bytes = R->edits.size(); R->pub.edit_bytes = R->edits.data();
-	R->pub.n_trace = R->trace.size(); R->pub.trace = R->trace.data();
 	*out = &R->pub;
+	if (getenv("GA_DEBUG_COLLECT"))
+	{
+		const auto t3 = std::chrono::steady_clock::now();
+		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		fprintf(stderr, "graphaligner_amd: collect: fetch %.1f ms (%zu trace bytes), assembly %.1f ms on %zu threads, stitch %.1f ms\n", ms(t0, t1), moves.size(), ms(t1, t2), nThreads, ms(t2, t3));
+	}
 	return GA_S_OK;
 }
 
