@@ -507,6 +507,10 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	b->names.resize(nReads);
 	b->seqs.resize(nReads);
 	auto pad64 = [](uint64_t n) { return (n + W - 1) / W * W; };
+	// the jobs are planned first (sizes and offsets only); their row codes, one byte per read base, are written afterwards by all host threads
+	struct RowFill { size_t read; uint64_t off, n, padded, pos; bool backward; };
+	std::vector<RowFill> fills;
+	uint64_t rowsTotal = 0;
 	for (size_t i = 0; i < nReads; i++)
 	{
 		b->names[i] = reads[i].name ? reads[i].name : "";
@@ -538,12 +542,11 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 				for (uint64_t r = 0; r < n; r++) if (!T.complement[(uint8_t)seq[r]]) { bad = true; break; }
 				if (bad) { sp.early = GA_S_ASSERTION; sp.valid = false; b->seeds.push_back(sp); continue; }
 				GaJob job;
-				job.rows_off = b->rows.size();
+				job.rows_off = rowsTotal;
 				job.n_rows = (uint32_t)pad64(n);
 				job.seed_node = bwNode;
-				b->rows.resize(b->rows.size() + job.n_rows, T.rowCode[(uint8_t)'N']);
-				uint8_t* dst = b->rows.data() + job.rows_off;
-				for (uint64_t r = 0; r < n; r++) dst[r] = T.rowCode[T.complement[(uint8_t)seq[n - 1 - r]]];
+				rowsTotal += job.n_rows;
+				fills.push_back(RowFill{i, job.rows_off, n, job.n_rows, 0, true});
 				sp.bwJob = (int64_t)b->jobs.size();
 				b->jobs.push_back(job);
 			}
@@ -551,12 +554,11 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 			{
 				uint64_t n = seq.size() - sp.pos;
 				GaJob job;
-				job.rows_off = b->rows.size();
+				job.rows_off = rowsTotal;
 				job.n_rows = (uint32_t)pad64(n);
 				job.seed_node = fwNode;
-				b->rows.resize(b->rows.size() + job.n_rows, T.rowCode[(uint8_t)'N']);
-				uint8_t* dst = b->rows.data() + job.rows_off;
-				for (uint64_t r = 0; r < n; r++) dst[r] = T.rowCode[(uint8_t)seq[sp.pos + r]];
+				rowsTotal += job.n_rows;
+				fills.push_back(RowFill{i, job.rows_off, n, job.n_rows, sp.pos, false});
 				sp.fwJob = (int64_t)b->jobs.size();
 				b->jobs.push_back(job);
 			}
@@ -568,7 +570,32 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		b->cfg.max_rows = std::max(b->cfg.max_rows, j.n_rows);
 		b->cfg.max_slices = std::max(b->cfg.max_slices, j.n_rows / W);
 	}
-	b->rows.resize(b->rows.size() + 64, 0);     // slack so a 64-byte row load never leaves the buffer
+	b->rows.assign(rowsTotal + 64, 0);          // (+ slack so a 64-byte row load never leaves the buffer)
+	{
+		size_t nThreads = std::thread::hardware_concurrency();
+		if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
+		nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), fills.size() / 64 + 1));
+		auto fill = [&](size_t lo, size_t hi) {
+			const uint8_t padCode = T.rowCode[(uint8_t)'N'];
+			for (size_t k = lo; k < hi; k++)
+			{
+				const RowFill& f = fills[k];
+				const std::string& seq = b->seqs[f.read];
+				uint8_t* dst = b->rows.data() + f.off;
+				if (f.backward) for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[T.complement[(uint8_t)seq[f.n - 1 - r]]];
+				else for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[(uint8_t)seq[f.pos + r]];
+				for (uint64_t r = f.n; r < f.padded; r++) dst[r] = padCode;
+			}
+		};
+		std::vector<std::thread> pool;
+		const size_t per = (fills.size() + nThreads - 1) / nThreads;
+		for (size_t t = 0; t < nThreads; t++)
+		{
+			const size_t lo = std::min(fills.size(), t * per), hi = std::min(fills.size(), lo + per);
+			if (lo < hi) pool.emplace_back(fill, lo, hi);
+		}
+		for (auto& th : pool) th.join();
+	}
 	int status = GA_S_OK;
 	b->dev = ga_backend_create_batch(g->device, b->rows, b->jobs, b->cfg, &status);
 	if (!b->dev) { delete b; return status ? status : GA_E_DEVICE; }
