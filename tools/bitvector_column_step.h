@@ -15,7 +15,13 @@
 #pragma once
 #include <stdint.h>
 
-static inline void bitvector_column_step(uint64_t& vp, uint64_t& vn, int& before, int calc, int flags, uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3)
+#ifdef __HIPCC__
+#define GA_BV_FN __host__ __device__ static inline
+#else
+#define GA_BV_FN static inline
+#endif
+
+GA_BV_FN void bitvector_column_step(uint64_t& vp, uint64_t& vn, int& before, int calc, int flags, uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3)
 {
 	uint64_t eq = (flags & 2) ? ((flags & 1) ? e3 : e2) : ((flags & 1) ? e1 : e0);
 	eq &= ~(uint64_t)((uint32_t)(flags >> 2) & 1u);
