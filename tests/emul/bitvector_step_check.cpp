@@ -65,5 +65,32 @@ int main()
 		reentries += d > 0;
 	}
 	printf("bitvector_column_step: %ld random columns agree with the cell recurrence (%ld with re-entry)\n", checked, reentries);
+	// ---- merge and value: two random valid columns, the merged words must encode the row-wise minimum ----
+	long merged = 0;
+	for (int trial = 0; trial < 100000; trial++)
+	{
+		int A[65], B[65];
+		uint64_t avp = 0, avn = 0, bvp = 0, bvn = 0;
+		A[0] = 50 + (int)(rng() % 20);
+		B[0] = 50 + (int)(rng() % 20);
+		for (int r = 0; r < 64; r++)
+		{
+			int d = (int)(rng() % 3) - 1, e = (int)(rng() % 3) - 1;
+			A[r + 1] = A[r] + d; B[r + 1] = B[r] + e;
+			if (d == 1) avp |= 1ull << r; else if (d == -1) avn |= 1ull << r;
+			if (e == 1) bvp |= 1ull << r; else if (e == -1) bvn |= 1ull << r;
+		}
+		uint64_t vp = avp, vn = avn;
+		int before = A[0];
+		bitvector_column_merge(vp, vn, before, bvp, bvn, B[0]);
+		if (before != (A[0] < B[0] ? A[0] : B[0]) || (vp & vn)) { printf("merge: before / overlap mismatch trial %d\n", trial); return 1; }
+		for (int r = 0; r < 64; r++)
+		{
+			const int want = A[r + 1] < B[r + 1] ? A[r + 1] : B[r + 1];
+			if (bitvector_column_value(vp, vn, before, r) != want) { printf("merge: row %d mismatch trial %d\n", r, trial); return 1; }
+		}
+		merged++;
+	}
+	printf("bitvector_column_merge / value: %ld random pairs agree with the row-wise minimum\n", merged);
 	return 0;
 }

@@ -62,3 +62,31 @@ GA_BV_FN void bitvector_column_step(uint64_t& vp, uint64_t& vn, int& before, int
 		before -= d;
 	}
 }
+
+// Cell-wise minimum of two columns over rows j-1 .. j+63 (mergeTwoSlices, WordSlice.h:361-421), row by row: what a node
+// start needs when the node has several in-neighbours in the band.  (The reference does this with byte-wise prefix sums in
+// O(log w); at one merge per node a 64-step loop per lane is affordable, and it is the form that was checked.)
+GA_BV_FN void bitvector_column_merge(uint64_t& vp, uint64_t& vn, int& before, uint64_t vp2, uint64_t vn2, int before2)
+{
+	int sa = before, sb = before2;
+	int prev = sa < sb ? sa : sb;
+	const int outBefore = prev;
+	uint64_t ovp = 0, ovn = 0;
+	for (int r = 0; r < 64; r++)
+	{
+		sa += (int)((vp >> r) & 1) - (int)((vn >> r) & 1);
+		sb += (int)((vp2 >> r) & 1) - (int)((vn2 >> r) & 1);
+		const int m = sa < sb ? sa : sb;
+		ovp |= (uint64_t)(m == prev + 1) << r;
+		ovn |= (uint64_t)(m == prev - 1) << r;
+		prev = m;
+	}
+	vp = ovp; vn = ovn; before = outBefore;
+}
+
+// score of row j+row of a column (WordSlice::getValue, WordSlice.h:223-229)
+GA_BV_FN int bitvector_column_value(uint64_t vp, uint64_t vn, int before, int row)
+{
+	const uint64_t mask = row < 63 ? ~(~0ull << (row + 1)) : ~0ull;
+	return before + __builtin_popcountll(vp & mask) - __builtin_popcountll(vn & mask);
+}
