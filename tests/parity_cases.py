@@ -173,6 +173,28 @@ def case_inversion_edges(lib_path=None):
     assert {m[1] for d in devs for m in d["mappings"]} == {0, 1}
 
 
+def case_reference_graph_plumbing(lib_path=None):
+    """the reference's own test graph (test/gwws_fail_ex1.vg, decoded fixture) and 10 reads of 256-290 bp cut
+    from its longest path with s = i = d = 0.03 (seed 1), seeded at the path's first node; plus the error-free longest-path read,
+    whose score SURVEY 8(c) recorded from the real engine (30)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "tests", "golden", "ref_gwws_fail_ex1.json")))
+    nodes = [tuple(x) for x in d["nodes"]]
+    edges = [tuple(x) for x in d["edges"]]
+    path, full = d["longest_path"], d["longest_path_read"]
+    rng = np.random.default_rng(1)
+    reads, seeds = [full], [(path[0], 0, False)]
+    for _ in range(10):
+        n = int(rng.integers(256, 291))
+        reads.append(synth.add_errors(np.frombuffer(full[:n].encode(), dtype=np.uint8), 0.03, 0.03, 0.03, rng).tobytes().decode())
+        seeds.append((path[0], 0, False))
+    devs, oras = pc.check_parity(nodes, edges, reads, seeds, 35, lib_path=lib_path, ctx="gwws")
+    assert devs[0]["status"] == 0 and devs[0]["score"] == 30
+    assert sum(1 for x in devs if x["status"] == 0 and not x["failed"]) >= 8
+
+
 def case_short_and_edge_reads(lib_path=None):
     """directions shorter than 193 bp hit assert(samplingFrequency > 1) in the reference
     (GraphAligner.h:906); seeds at the last base align backwards only (:3006)"""

@@ -40,6 +40,10 @@ def test_inversion_edges(lib):
     cases.case_inversion_edges(lib)
 
 
+def test_reference_graph_plumbing(lib):
+    cases.case_reference_graph_plumbing(lib)
+
+
 def test_short_and_edge_reads(lib):
     cases.case_short_and_edge_reads(lib)
 

@@ -42,6 +42,10 @@ def test_inversion_edges():
     cases.case_inversion_edges()
 
 
+def test_reference_graph_plumbing():
+    cases.case_reference_graph_plumbing()
+
+
 def test_short_and_edge_reads():
     cases.case_short_and_edge_reads()
 
