@@ -69,5 +69,27 @@ public:
 
 // returns nullptr + sets *status (GA_E_NO_DEVICE ...) on failure
 GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& g, const GaHmmTables& hmm, int device, int* status);
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, const std::vector<uint8_t>& rows, const std::vector<GaJob>& jobs,
+// eq: per job and 64-row slice five 64-bit words (job j, slice s at (jobs[j].rows_off / 64 + s) * 5): the match words of the slice's rows
+// against A, C, G, T and a meta word (bits 0-2 exact-compare code of the slice's last row, bit 3 = a row with an invalid character)
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status);
+
+// the match words of ga_backend_create_batch from the row codes
+inline void ga_build_eq_words(const uint8_t* rows, uint64_t nRows, uint64_t* eq)
+{
+	for (uint64_t s = 0; s < nRows / 64; s++)
+	{
+		uint64_t e[4] = {0, 0, 0, 0};
+		uint32_t invalid = 0;
+		const uint8_t* r = rows + s * 64;
+		for (int i = 0; i < 64; i++)
+		{
+			const uint8_t c = r[i];
+			for (int b = 0; b < 4; b++) e[b] |= (uint64_t)((c >> b) & 1) << i;
+			invalid |= c & GA_ROW_INVALID;
+		}
+		uint64_t* o = eq + s * 5;
+		o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = e[3];
+		o[4] = (uint64_t)((r[63] >> 4) & 7) | (invalid ? 8u : 0u);
+	}
+}

@@ -204,6 +204,7 @@ struct ga_batch
 	std::vector<ReadPlan> reads;
 	std::vector<SeedPlan> seeds;
 	std::vector<uint8_t> rows;
+	std::vector<uint64_t> eq;
 	std::vector<GaJob> jobs;
 	GaRunConfig cfg;
 	uint32_t flags = 0;
@@ -238,7 +239,7 @@ int mapDeviceStatus(int s)
 		case GA_UNSUPPORTED_BAND: return GA_S_UNSUPPORTED_BAND;
 		case GA_UNSUPPORTED_CYCLE: return GA_S_UNSUPPORTED_CYCLE;
 		case GA_UNSUPPORTED_RAMP: return GA_S_UNSUPPORTED_RAMP;
-		case GA_CAP_NODES: case GA_CAP_COLS: case GA_CAP_ARENA: case GA_CAP_TRACE: case GA_CAP_HEAP: return GA_S_CAPACITY;
+		case GA_CAP_NODES: case GA_CAP_COLS: case GA_CAP_ARENA: case GA_CAP_TRACE: case GA_CAP_HEAP: case GA_PUNT: return GA_S_CAPACITY;
 		default: return GA_E_DEVICE;
 	}
 }
@@ -571,6 +572,7 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		b->cfg.max_slices = std::max(b->cfg.max_slices, j.n_rows / W);
 	}
 	b->rows.assign(rowsTotal + 64, 0);          // (+ slack so a 64-byte row load never leaves the buffer)
+	b->eq.assign((rowsTotal / W + 1) * 5, 0);   // match words per slice for the lanes = reads kernel
 	{
 		size_t nThreads = std::thread::hardware_concurrency();
 		if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
@@ -585,6 +587,7 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 				if (f.backward) for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[T.complement[(uint8_t)seq[f.n - 1 - r]]];
 				else for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[(uint8_t)seq[f.pos + r]];
 				for (uint64_t r = f.n; r < f.padded; r++) dst[r] = padCode;
+				ga_build_eq_words(dst, f.padded, b->eq.data() + f.off / W * 5);
 			}
 		};
 		std::vector<std::thread> pool;
@@ -597,7 +600,7 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		for (auto& th : pool) th.join();
 	}
 	int status = GA_S_OK;
-	b->dev = ga_backend_create_batch(g->device, b->rows, b->jobs, b->cfg, &status);
+	b->dev = ga_backend_create_batch(g->device, b->rows, b->eq, b->jobs, b->cfg, &status);
 	if (!b->dev) { delete b; return status ? status : GA_E_DEVICE; }
 	*out = b;
 	return GA_S_OK;

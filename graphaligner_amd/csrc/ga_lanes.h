@@ -1,0 +1,903 @@
+// ga_lanes.h -- the extension program with LANES = READS: every lane of a wavefront owns one read direction
+// (one extension job) and carries it through band selection, slice fill and traceback on its own; the 64 lanes
+// of a wave advance slice by slice in lockstep.
+//
+// Why: the wave-per-read program (ga_kernel.h, lanes = rows) spends ~19 vector instructions per graph column on
+// a six-step cross-lane scan and is bound by vector-instruction issue at 6.8 % of the HBM roofline.  Here a
+// column is the reference's own bit-vector step (getNextSlice, GraphAligner.h:1349-1427) on a lane's private
+// 64-bit VP/VN words: ~100 instructions advance 64 reads by one column each.
+//
+// What a lane computes is exactly what ga_kernel.h computes for jobs whose bands have no cycle and that never
+// take the ramp redo; anything else (a cyclic band, a ramp redo, a band wider than the lane's LDS tables, node
+// degrees above four, reads shorter than four slices ...) ends the lane's job with a status that sends it to
+// the wave-per-read ladder, which carries those paths.  Results are bit-identical either way.
+//
+// Memory, all sized per wave:
+//   LDS      per-lane band tables, [word][lane] interleaved (bank = lane: never a conflict), 10 * MAXN words per lane
+//   HBM      end words of the previous / current slice  [column][lane]                       (4 B per column)
+//            slice records: VP, VN, scoreBeforeStart, end word = 24 B per column, in blocks of R columns per lane
+//            per-slice headers and band node lists for the traceback, [slice][k][lane]
+//            traceback moves, 4 per word, [k][lane]
+//
+// The same source builds for gfx950 and, with GA_EMULATE, for the host (tests only): a lane's program is plain
+// scalar code; the few wave-level decisions (loop while ANY lane has work, the slice's row range = MAX over
+// lanes) sit in the driver at the bottom.
+#pragma once
+#include <stdint.h>
+
+#include "ga_types.h"
+
+namespace gal {
+
+#ifdef GA_EMULATE
+#define GAL_FN inline
+#else
+#define GAL_FN __device__ __forceinline__
+#endif
+
+constexpr int W = 64;
+constexpr int INF = 0x3fffffff;
+constexpr uint32_t kCutoff = 200000;          // GraphAlignerCommon.h:10
+constexpr int kRecBytes = 24;                 // VP 8, VN 8, scoreBeforeStart 4, end word 4
+constexpr int kHdrWords = 8;                  // per slice and lane: nNodes, nCols, minScore, minSlot, minOffset, flags, rowBase, spare
+constexpr uint32_t kNone = 0xffu;
+
+// end word of a column: scoreEnd << 3 | scoreBeforeExists << 2 | VN bit 63 << 1 | VP bit 63
+GAL_FN int ew_end(uint32_t e) { return (int)(e >> 3); }
+GAL_FN int ew_end2(uint32_t e) { return (int)(e >> 3) - (int)(e & 1) + (int)((e >> 1) & 1); }       // score one row above the end (row 62)
+
+// launch parameters of the lanes kernel
+struct GaLanesLaunch
+{
+	GaDevGraph graph;
+	const GaHmmTables* hmm;
+	const uint64_t* eq;            // per job and slice: 4 match words (A, C, G, T) + 1 meta word (bits 0-2 exact code of row 63, bit 3 an invalid row)
+	const GaJob* jobs;
+	GaJobOut* outs;
+	const uint32_t* job_list;      // wave g takes jobs job_list[g * lanes_per_wave + lane]; nullptr = identity
+	uint32_t n_jobs;
+	uint32_t lanes_per_wave;       // 64, or fewer to put more waves on a SIMD
+	uint32_t* next_group;          // device work counter
+	uint8_t* scratch;              // [n_waves][wave_bytes]
+	uint64_t wave_bytes;
+	uint8_t* traces;               // trace pool (bytes), shared with the ladder kernels
+	uint64_t* trace_top;
+	uint64_t trace_pool_cap;
+	uint32_t cap_cols;             // columns per slice (end planes)
+	uint32_t cap_rows;             // arena rows per wave (sum over slices of the widest lane's band)
+	uint32_t max_slices;
+	uint32_t cap_moves;            // traceback moves per lane (staging)
+	int32_t initial_bw, ramp_bw;
+};
+
+// byte offsets inside a wave's scratch region
+struct WaveLayout { uint64_t endA, endB, hdr, snodes, moves, arena, bytes; };
+template <int N>
+inline
+#ifndef GA_EMULATE
+__host__ __device__
+#endif
+WaveLayout wave_layout(uint32_t capCols, uint32_t capRows, uint32_t maxSlices, uint32_t capMoves)
+{
+	auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
+	WaveLayout l;
+	uint64_t at = 0;
+	l.endA = at; at = up(at + 256ull * (capCols + 16));
+	l.endB = at; at = up(at + 256ull * (capCols + 16));
+	l.hdr = at; at = up(at + 256ull * kHdrWords * (maxSlices + 1));
+	l.snodes = at; at = up(at + 256ull * 2 * N * (maxSlices + 1));
+	l.moves = at; at = up(at + 256ull * ((capMoves + 3) / 4 + 1));
+	l.arena = at; at = up(at + (uint64_t)kRecBytes * 64 * (capRows + 16));
+	l.bytes = at;
+	return l;
+}
+
+// where the record of (arena row, lane) lives: blocks of R consecutive rows of one lane are contiguous
+template <int R> GAL_FN uint64_t rec_off(uint32_t row, int lane)
+{
+	return ((uint64_t)(row / R) * 64 + (uint32_t)lane) * (R * kRecBytes) + (uint64_t)(row % R) * kRecBytes;
+}
+
+// ---- per-lane LDS tables: word i of lane l sits at lds[i * LW + l] ------------------------------------------------
+template <int N> struct Lay
+{
+	static constexpr int H = 2 * N;                   // heap entries
+	static constexpr int HB = N <= 13 ? 13 : N <= 29 ? 29 : N <= 59 ? 59 : 127;      // buckets the frozen map can grow to with N keys
+	static constexpr int P_NODE = 0, P_END = N, P_PACK = 2 * N;                      // previous band: node, end word of its last column, colBase | (min - sliceMin) << 16
+	static constexpr int C_NODE = 3 * N, C_GEO = 4 * N, C_PINFO = 5 * N;             // current band: node, colBase | len << 16, prev colBase | prev slot << 16
+	static constexpr int X = 6 * N;
+	// while the band is selected: hash-order bytes, heap
+	static constexpr int X_HASH = X, X_HEAPN = X + N, X_HEAPP = X + N + H;
+	static constexpr int HB_ORDER = 0, HB_NEXT = N, HB_BEFORE = 2 * N;                // byte offsets inside X_HASH
+	// while the slice is filled: node minimum, end word of the node's last column, out-neighbour slots, order bytes
+	static constexpr int C_MIN = X, C_END = X + N, C_OUT = X + 2 * N, X_ORD = X + 3 * N;
+	static constexpr int OB_POST = 0, OB_COLOR = N, OB_STSLOT = 2 * N, OB_STCUR = 3 * N;
+	// during the traceback: node lists of the slice traced through and of the slice above it
+	static constexpr int T_CN = 0, T_CB = N, T_PN = 2 * N, T_PB = 3 * N;
+	static constexpr int WORDS = 10 * N;
+	static_assert((2 * N + HB + 3) / 4 <= N, "hash bytes do not fit");
+};
+
+struct Lds
+{
+	uint32_t* base;     // already offset by the lane
+	int lw;             // lane stride in words
+	GAL_FN uint32_t rd(int i) const { return base[i * lw]; }
+	GAL_FN void wr(int i, uint32_t v) const { base[i * lw] = v; }
+	GAL_FN uint32_t rdh(int word, int k) const { return ((const uint16_t*)(base + (word + (k >> 1)) * lw))[k & 1]; }
+	GAL_FN void wrh(int word, int k, uint32_t v) const { ((uint16_t*)(base + (word + (k >> 1)) * lw))[k & 1] = (uint16_t)v; }
+	GAL_FN uint32_t rdb(int word, int k) const { return ((const uint8_t*)(base + (word + (k >> 2)) * lw))[k & 3]; }
+	GAL_FN void wrb(int word, int k, uint32_t v) const { ((uint8_t*)(base + (word + (k >> 2)) * lw))[k & 3] = (uint8_t)v; }
+};
+
+// a lane's view of its wave's HBM scratch: plane[k * 64] is entry k of this lane
+struct LaneMem
+{
+	Lds lds;
+	uint32_t* endPrev;
+	uint32_t* endCur;
+	uint32_t* hdr;
+	uint32_t* snodes;
+	uint32_t* moves;
+	uint8_t* arena;
+	int lane;
+};
+
+// what a lane carries from slice to slice
+struct LaneState
+{
+	uint32_t job, nRows, numSlices, seedNode;
+	const uint64_t* eq;
+	int status;
+	bool live;                    // still in the slice loop
+	int pn, cn;
+	int prevMin;
+	uint32_t totalCols;
+	uint32_t rowBase;             // arena row of this slice's first column
+	uint64_t e0, e1, e2, e3;
+	int rawAbove;                 // exact-compare code of the read character of row j-1 (7 = none)
+	int sliceMin, minSlot;
+	uint32_t minOffset;
+	double logCorrect, logWrong;
+	uint32_t nPushed, nRun, maxBandNodes, kept;
+	uint64_t nColumns;
+	uint32_t rampUntil;
+	bool useRamp;
+};
+
+// ---- graph access ---------------------------------------------------------------------------------------------
+GAL_FN const uint32_t* g_rec(const GaDevGraph& g, uint32_t node) { return g.node_rec + (uint64_t)node * GA_NODE_REC_WORDS; }
+
+GAL_FN int find_in(const Lds& l, int table, int count, uint32_t key)
+{
+	int found = -1;
+	for (int k = 0; k < count; k++) if (l.rd(table + k) == key) found = found < 0 ? k : found;
+	return found;
+}
+
+// ---- std::unordered_map<size_t,..> iteration order after inserting the previous band's nodes one by one --------
+// (NodeSlice.h:728-738 builds the frozen slice's map so; GraphAligner.h:1117 iterates it).  libstdc++: identity hash,
+// bucket = key % B, B grows 13, 29, 59, 127 when the size would exceed it; a node entering an empty bucket becomes the
+// list head, otherwise it goes behind its bucket's "before" node; a rehash re-inserts the nodes in iteration order.
+template <int N> GAL_FN void hash_insert(const Lds& l, int i, uint32_t B, int& head)
+{
+	typedef Lay<N> LY;
+	const uint32_t b = l.rd(LY::P_NODE + i) % B;
+	const uint32_t before = l.rdb(LY::X_HASH, LY::HB_BEFORE + (int)b);
+	if (before != 0xffu)
+	{
+		if (before == 0xfeu) { l.wrb(LY::X_HASH, LY::HB_NEXT + i, (uint32_t)head & 0xffu); head = i; }
+		else { l.wrb(LY::X_HASH, LY::HB_NEXT + i, l.rdb(LY::X_HASH, LY::HB_NEXT + (int)before)); l.wrb(LY::X_HASH, LY::HB_NEXT + (int)before, (uint32_t)i); }
+	}
+	else
+	{
+		l.wrb(LY::X_HASH, LY::HB_NEXT + i, (uint32_t)head & 0xffu);
+		if (head >= 0) l.wrb(LY::X_HASH, LY::HB_BEFORE + (int)(l.rd(LY::P_NODE + head) % B), (uint32_t)i);
+		head = i;
+		l.wrb(LY::X_HASH, LY::HB_BEFORE + (int)b, 0xfeu);
+	}
+}
+template <int N> GAL_FN void hash_order(const Lds& l, int n)
+{
+	typedef Lay<N> LY;
+	uint32_t B = 13;
+	int head = -1;
+	for (int b = 0; b < 13; b++) l.wrb(LY::X_HASH, LY::HB_BEFORE + b, 0xffu);
+	for (int i = 0; i < n; i++)
+	{
+		const uint32_t grown = i == 13 ? 29u : i == 29 ? 59u : i == 59 ? 127u : 0u;
+		if (grown)
+		{
+			int k = 0;
+			for (int p = head; p >= 0; ) { l.wrb(LY::X_HASH, LY::HB_ORDER + k, (uint32_t)p); k++; const uint32_t nx = l.rdb(LY::X_HASH, LY::HB_NEXT + p); p = nx == 0xffu ? -1 : (int)nx; }
+			B = grown;
+			head = -1;
+			for (uint32_t b = 0; b < B; b++) l.wrb(LY::X_HASH, LY::HB_BEFORE + (int)b, 0xffu);
+			for (int q = 0; q < k; q++) hash_insert<N>(l, (int)l.rdb(LY::X_HASH, LY::HB_ORDER + q), B, head);
+		}
+		hash_insert<N>(l, i, B, head);
+	}
+	int k = 0;
+	for (int p = head; p >= 0; ) { l.wrb(LY::X_HASH, LY::HB_ORDER + k, (uint32_t)p); k++; const uint32_t nx = l.rdb(LY::X_HASH, LY::HB_NEXT + p); p = nx == 0xffu ? -1 : (int)nx; }
+}
+
+// ---- std::priority_queue<.., std::greater<>> over (node, priority): libstdc++'s __push_heap / __adjust_heap ------
+// (GraphAligner.h:1115; the pop order among equal priorities decides DPSlice::nodes order)
+template <int N> GAL_FN void heap_sift_up(const Lds& l, int hole, uint32_t node, uint32_t prio)
+{
+	typedef Lay<N> LY;
+	int parent = (hole - 1) / 2;
+	while (hole > 0 && l.rdh(LY::X_HEAPP, parent) > prio)
+	{
+		l.wrh(LY::X_HEAPP, hole, l.rdh(LY::X_HEAPP, parent));
+		l.wr(LY::X_HEAPN + hole, l.rd(LY::X_HEAPN + parent));
+		hole = parent;
+		parent = (hole - 1) / 2;
+	}
+	l.wrh(LY::X_HEAPP, hole, prio);
+	l.wr(LY::X_HEAPN + hole, node);
+}
+template <int N> GAL_FN bool heap_push(const Lds& l, int& size, uint32_t node, int prio)
+{
+	if (size >= Lay<N>::H || prio < 0 || prio > 0xffff) return false;
+	size++;
+	heap_sift_up<N>(l, size - 1, node, (uint32_t)prio);
+	return true;
+}
+template <int N> GAL_FN void heap_pop(const Lds& l, int& size)
+{
+	typedef Lay<N> LY;
+	// std::pop_heap then pop_back: the last element is re-inserted from the root
+	const int len = size - 1;
+	const uint32_t node = l.rd(LY::X_HEAPN + len), prio = l.rdh(LY::X_HEAPP, len);
+	size = len;
+	if (len == 0) return;
+	int hole = 0, child = 0;
+	while (child < (len - 1) / 2)
+	{
+		child = 2 * (child + 1);
+		if (l.rdh(LY::X_HEAPP, child) > l.rdh(LY::X_HEAPP, child - 1)) child--;
+		l.wrh(LY::X_HEAPP, hole, l.rdh(LY::X_HEAPP, child));
+		l.wr(LY::X_HEAPN + hole, l.rd(LY::X_HEAPN + child));
+		hole = child;
+	}
+	if ((len & 1) == 0 && child == (len - 2) / 2)
+	{
+		child = 2 * (child + 1);
+		l.wrh(LY::X_HEAPP, hole, l.rdh(LY::X_HEAPP, child - 1));
+		l.wr(LY::X_HEAPN + hole, l.rd(LY::X_HEAPN + child - 1));
+		hole = child - 1;
+	}
+	heap_sift_up<N>(l, hole, node, prio);
+}
+
+// ---- band selection at node granularity (projectForwardFromMinScore, GraphAligner.h:1110-1159) -------------------
+template <int N> GAL_FN int project_band(const GaDevGraph& g, const LaneMem& m, LaneState& st, int bandwidth)
+{
+	typedef Lay<N> LY;
+	const Lds& l = m.lds;
+	const int pn = st.pn, prevMin = st.prevMin, expand = bandwidth + W;
+	int cn = 0, heapSize = 0;
+	uint32_t totalCols = 0;
+	hash_order<N>(l, pn);
+	auto add = [&](uint32_t node, int prevSlot, uint32_t len, uint32_t prevBase) -> int {
+		if (cn >= N) return GA_CAP_NODES;
+		if (len > 0xffffu || totalCols + len > 0xffffu) return GA_CAP_COLS;
+		l.wr(LY::C_NODE + cn, node);
+		l.wr(LY::C_GEO + cn, totalCols | (len << 16));
+		l.wr(LY::C_PINFO + cn, prevSlot >= 0 ? (prevBase | ((uint32_t)prevSlot << 16)) : (kNone << 16));
+		totalCols += len;
+		cn++;
+		return totalCols >= kCutoff ? GA_UNSUPPORTED_BAND : GA_OK;
+	};
+	auto pushOut = [&](const uint32_t* rec, uint32_t node, int prio) -> int {
+		const uint32_t deg = rec[3] >> 16;
+		if (deg <= 4) { for (uint32_t e = 0; e < deg; e++) if (!heap_push<N>(l, heapSize, rec[4 + e], prio)) return GA_CAP_HEAP; }
+		else for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++) if (!heap_push<N>(l, heapSize, g.out_nbr[e], prio)) return GA_CAP_HEAP;
+		return GA_OK;
+	};
+	for (int k = 0; k < pn; k++)
+	{
+		const int s = (int)l.rdb(LY::X_HASH, LY::HB_ORDER + k);
+		const uint32_t pack = l.rd(LY::P_PACK + s);
+		if ((int)(pack >> 16) > bandwidth) continue;                              // node.minScore <= minScore + bandwidth (:1119)
+		const uint32_t node = l.rd(LY::P_NODE + s);
+		const uint32_t* rec = g_rec(g, node);
+		int rc = add(node, s, rec[2], pack & 0xffffu);
+		if (rc != GA_OK) return rc;
+		const int endScore = ew_end(l.rd(LY::P_END + s));
+		if (endScore > prevMin + expand) continue;
+		rc = pushOut(rec, node, endScore - prevMin + 1);
+		if (rc != GA_OK) return rc;
+	}
+	if (cn == 0) return GA_ASSERTION;                                             // assert(distances.size() > 0) (:1138)
+	while (heapSize > 0)
+	{
+		const uint32_t node = l.rd(LY::X_HEAPN);
+		const int prio = (int)l.rdh(LY::X_HEAPP, 0);
+		if (prio > expand) break;
+		heap_pop<N>(l, heapSize);
+		if (find_in(l, LY::C_NODE, cn, node) >= 0) continue;                      // already at a distance <= prio
+		const int ps = find_in(l, LY::P_NODE, pn, node);
+		const uint32_t* rec = g_rec(g, node);
+		const uint32_t len = rec[2];
+		int rc = add(node, ps, len, ps >= 0 ? (l.rd(LY::P_PACK + ps) & 0xffffu) : 0u);
+		if (rc != GA_OK) return rc;
+		rc = pushOut(rec, node, prio + (int)len);
+		if (rc != GA_OK) return rc;
+	}
+	st.cn = cn;
+	st.totalCols = totalCols;
+	return GA_OK;
+}
+
+// ---- out-neighbour slots and the processing order: reverse Tarjan emission order over the band subgraph ---------
+// (GraphAligner.h:1836-1901, :2360).  On a DAG every node is its own component, emitted when its DFS finishes.
+template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, LaneState& st)
+{
+	typedef Lay<N> LY;
+	const Lds& l = m.lds;
+	const int cn = st.cn;
+	for (int s = 0; s < cn; s++)
+	{
+		const uint32_t* rec = g_rec(g, l.rd(LY::C_NODE + s));
+		const uint32_t outDeg = rec[3] >> 16, inDeg = rec[3] & 0xffffu;
+		if (outDeg > 4 || inDeg > 4) return GA_PUNT;
+		uint32_t slots = 0;
+		for (uint32_t e = 0; e < 4; e++)
+		{
+			int x = -1;
+			if (e < outDeg) x = find_in(l, LY::C_NODE, cn, rec[4 + e]);
+			slots |= (x < 0 ? kNone : (uint32_t)x) << (8 * e);
+		}
+		l.wr(LY::C_OUT + s, slots);
+		l.wrb(LY::X_ORD, LY::OB_COLOR + s, 0);
+	}
+	int emitted = 0;
+	for (int root = 0; root < cn; root++)
+	{
+		if (l.rdb(LY::X_ORD, LY::OB_COLOR + root) != 0) continue;
+		int sp = 1;
+		l.wrb(LY::X_ORD, LY::OB_COLOR + root, 1);
+		l.wrb(LY::X_ORD, LY::OB_STSLOT, (uint32_t)root);
+		l.wrb(LY::X_ORD, LY::OB_STCUR, 0);
+		while (sp > 0)
+		{
+			const int v = (int)l.rdb(LY::X_ORD, LY::OB_STSLOT + sp - 1);
+			const int cur = (int)l.rdb(LY::X_ORD, LY::OB_STCUR + sp - 1);
+			if (cur < 4)
+			{
+				const uint32_t x = (l.rd(LY::C_OUT + v) >> (8 * cur)) & 0xffu;
+				const uint32_t color = x == kNone ? 2u : l.rdb(LY::X_ORD, LY::OB_COLOR + (int)x);
+				if (color == 2) { l.wrb(LY::X_ORD, LY::OB_STCUR + sp - 1, (uint32_t)(cur + 1)); continue; }
+				if (color == 1) return GA_UNSUPPORTED_CYCLE;
+				l.wrb(LY::X_ORD, LY::OB_COLOR + (int)x, 1);
+				l.wrb(LY::X_ORD, LY::OB_STSLOT + sp, x);
+				l.wrb(LY::X_ORD, LY::OB_STCUR + sp, 0);
+				sp++;
+				continue;
+			}
+			l.wrb(LY::X_ORD, LY::OB_COLOR + v, 2);
+			l.wrb(LY::X_ORD, LY::OB_POST + emitted, (uint32_t)v);
+			emitted++;
+			sp--;
+			if (sp > 0) l.wrb(LY::X_ORD, LY::OB_STCUR + sp - 1, l.rdb(LY::X_ORD, LY::OB_STCUR + sp - 1) + 1);
+		}
+	}
+	return GA_OK;
+}
+
+// ---- one column step in the reference's bit-vector form ------------------------------------------------------------
+// getNextSlice (GraphAligner.h:1349-1427) without the row confirmation only cycles need, then the vertical re-entry of
+// calculateNode (:1541-1546) as the cell-wise minimum with the run coming down from the cell above (score `calc - d`):
+// with T_r = S_r - r the run is constant and the column loses one unit at every row without VP and one more with VN,
+// so the run wins down to the row where d units are lost.
+struct Col { uint64_t vp, vn; int before; };
+
+GAL_FN void column_step(Col& c, uint64_t eq, bool noDiag, int calc)
+{
+	if (noDiag) eq &= ~1ull;
+	const int hin = calc - c.before;
+	const uint64_t neg = (uint32_t)hin >> 31, pos = (uint32_t)(-hin) >> 31;
+	const uint64_t xv = eq | c.vn;
+	eq |= neg;
+	const uint64_t xh = (((eq & c.vp) + c.vp) ^ c.vp) | eq;
+	uint64_t ph = c.vn | ~(xh | c.vp);
+	uint64_t mh = c.vp & xh;
+	ph = (ph << 1) | pos;
+	mh = (mh << 1) | neg;
+	c.vp = mh | ~(xv | ph);
+	c.vn = ph & xv;
+	c.before = calc;
+}
+GAL_FN void column_reenter(Col& c, int d)
+{
+	int lost = 0, p = 64;
+	bool exact = false;
+	uint64_t mz = ~c.vp;
+	while (mz)
+	{
+		const int i = __builtin_ctzll(mz);
+		mz &= mz - 1;
+		lost += 1 + (int)((c.vn >> i) & 1);
+		if (lost >= d) { p = i; exact = lost == d; break; }
+	}
+	const uint64_t below = p >= 64 ? ~0ull : ((1ull << p) - 1);
+	const uint64_t keep = p >= 63 ? 0ull : (~0ull << (p + 1));
+	c.vp = below | (c.vp & keep) | ((p < 64 && exact) ? (1ull << p) : 0ull);
+	c.vn = c.vn & keep;
+	c.before -= d;
+}
+// cell-wise minimum of two columns over rows j-1 .. j+63 (mergeTwoSlices, WordSlice.h:361-421), row by row
+GAL_FN void column_merge(Col& a, const Col& b)
+{
+	int sa = a.before, sb = b.before;
+	int prev = sa < sb ? sa : sb;
+	const int outBefore = prev;
+	uint64_t ovp = 0, ovn = 0;
+	for (int r = 0; r < 64; r++)
+	{
+		sa += (int)((a.vp >> r) & 1) - (int)((a.vn >> r) & 1);
+		sb += (int)((b.vp >> r) & 1) - (int)((b.vn >> r) & 1);
+		const int mn = sa < sb ? sa : sb;
+		ovp |= (uint64_t)(mn == prev + 1) << r;
+		ovn |= (uint64_t)(mn == prev - 1) << r;
+		prev = mn;
+	}
+	a.vp = ovp; a.vn = ovn; a.before = outBefore;
+}
+GAL_FN int col_end(const Col& c) { return c.before + __builtin_popcountll(c.vp) - __builtin_popcountll(c.vn); }
+GAL_FN int col_value(uint64_t vp, uint64_t vn, int before, int row)            // WordSlice::getValue (WordSlice.h:223-229)
+{
+	const uint64_t mask = row < 63 ? ~(~0ull << (row + 1)) : ~0ull;
+	return before + __builtin_popcountll(vp & mask) - __builtin_popcountll(vn & mask);
+}
+
+template <int R> GAL_FN void rec_store(const LaneMem& m, uint32_t row, const Col& c, uint32_t endWord)
+{
+	uint32_t* p = (uint32_t*)(m.arena + rec_off<R>(row, m.lane));
+	p[0] = (uint32_t)c.vp; p[1] = (uint32_t)(c.vp >> 32); p[2] = (uint32_t)c.vn; p[3] = (uint32_t)(c.vn >> 32);
+	p[4] = (uint32_t)c.before; p[5] = endWord;
+}
+template <int R> GAL_FN void rec_load(const LaneMem& m, uint32_t row, Col& c, uint32_t& endWord)
+{
+	const uint32_t* p = (const uint32_t*)(m.arena + rec_off<R>(row, m.lane));
+	c.vp = ((uint64_t)p[1] << 32) | p[0];
+	c.vn = ((uint64_t)p[3] << 32) | p[2];
+	c.before = (int)p[4];
+	endWord = p[5];
+}
+
+GAL_FN uint64_t eq_for(const LaneState& st, int base)
+{
+	return (base & 2) ? ((base & 1) ? st.e3 : st.e2) : ((base & 1) ? st.e1 : st.e0);
+}
+GAL_FN int g_base(const GaDevGraph& g, uint64_t col) { return (int)((g.seq2[col >> 4] >> ((col & 15) * 2)) & 3); }
+
+// ---- fill one slice: every band node in processing order (calculateSlice / calculateNode, GraphAligner.h:2331-2451,
+// 1457-1573), one column per step.  The bookkeeping of the virtual row j-1 (forceComponentZeroRow's chain :1939-1944,
+// scoreBeforeStart / scoreBeforeExists of getNextSlice :1358-1370, the re-entry test :1541-1546) runs along the node
+// with the columns.
+template <int N, int R>
+GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uint32_t slice, bool active)
+{
+	typedef Lay<N> LY;
+	const Lds& l = m.lds;
+	const bool j0 = slice == 0;
+	const int pn = st.pn, cn = st.cn;
+	int ord = active ? cn - 1 : -1;
+	int sliceMin = INF, minSlot = -1;
+	uint32_t minOffset = 0;
+	int status = GA_OK;
+#ifdef GA_EMULATE
+	while (ord >= 0)
+#else
+	while (__ballot(ord >= 0))
+#endif
+	{
+		if (ord < 0) continue;
+		const int s = (int)l.rdb(LY::X_ORD, LY::OB_POST + ord);
+		const uint32_t node = l.rd(LY::C_NODE + s);
+		const uint32_t geo = l.rd(LY::C_GEO + s), pinfo = l.rd(LY::C_PINFO + s);
+		const uint32_t colBase = geo & 0xffffu, len = geo >> 16;
+		const bool inPrev = (pinfo >> 16) != kNone;
+		const uint32_t pbase = pinfo & 0xffffu;
+		const uint32_t* rec = g_rec(g, node);
+		const uint64_t firstCol = ((uint64_t)rec[1] << 32) | rec[0];
+		const uint32_t inDeg = rec[3] & 0xffffu;
+		const bool aboveAlways = j0 && inPrev;                                   // "previousEq" (:1503): raw char ==, not characterMatch
+		const uint32_t* pend = m.endPrev + (uint64_t)pbase * 64;
+		// ---- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ----
+		const uint32_t pend0raw = inPrev ? pend[0] : 0u;
+		const int pend0 = inPrev ? ew_end(pend0raw) : INF;
+		int zero0 = pend0;
+		bool hasIn = false;
+		int cs[4], pm[4];
+		Col left[4];
+		uint32_t leftEw[4];
+		for (uint32_t e = 0; e < 4; e++)
+		{
+			cs[e] = -1; pm[e] = -1; leftEw[e] = 0; left[e].vp = 0; left[e].vn = 0; left[e].before = 0;
+			if (e >= inDeg) continue;
+			const uint32_t nb = rec[8 + e];
+			cs[e] = find_in(l, LY::C_NODE, cn, nb);
+			pm[e] = find_in(l, LY::P_NODE, pn, nb);
+			if (cs[e] < 0 && pm[e] < 0) continue;
+			hasIn = true;
+			if (cs[e] >= 0)
+			{
+				const uint32_t ng = l.rd(LY::C_GEO + cs[e]);
+				rec_load<R>(m, st.rowBase + (ng & 0xffffu) + (ng >> 16) - 1, left[e], leftEw[e]);
+				zero0 = zero0 < left[e].before + 1 ? zero0 : left[e].before + 1;
+			}
+			if (pm[e] >= 0)
+			{
+				const int pe = ew_end(l.rd(LY::P_END + pm[e]));
+				zero0 = zero0 < pe + 1 ? zero0 : pe + 1;
+			}
+		}
+		const int base0 = g_base(g, firstCol);
+		const uint64_t eq0 = eq_for(st, base0);
+		const bool aboveEq0 = aboveAlways || (!j0 && st.rawAbove == base0);
+		const bool exists0 = inPrev && pend0 == zero0;                           // scoreBeforeExists from :1989 (scoreEndExists is always true on this path)
+		Col c;
+		bool exists;
+		if (!hasIn)
+		{
+			// source node (:1475-1499): a vertical run from the cell above
+			if (j0 && inPrev) { c.vp = ~1ull | (uint64_t)(((eq0 & 1) != 0) ? 0 : 1); c.vn = 0; c.before = pend0; exists = true; }
+			else if (inPrev) { c.vp = ~0ull; c.vn = 0; c.before = pend0; exists = true; }
+			else { c.vp = ~1ull; c.vn = 0; c.before = (int)st.nRows + 1; exists = false; }
+		}
+		else
+		{
+			// node start: cell-wise minimum over the in-neighbours' last columns advanced one step (getNodeStartSlice :1270-1315)
+			bool first = true;
+			c.vp = 0; c.vn = 0; c.before = 0;
+			for (uint32_t e = 0; e < 4; e++)
+			{
+				if (cs[e] < 0 && pm[e] < 0) continue;
+				Col x;
+				uint64_t eq = eq0;
+				bool leftExists;
+				if (cs[e] >= 0) { x = left[e]; leftExists = ((leftEw[e] >> 2) & 1) != 0; }
+				else
+				{
+					// neighbour only in the previous band: vertical source column, only row j may match (:1294-1301)
+					x.vp = ~0ull; x.vn = 0; x.before = ew_end(l.rd(LY::P_END + pm[e]));
+					leftExists = true;
+					eq &= 1ull;
+				}
+				int calc = x.before + 1;
+				if (exists0 && pm[e] >= 0)
+				{
+					const int viaDiag = ew_end2(l.rd(LY::P_END + pm[e])) + (aboveEq0 ? 0 : 1);
+					calc = calc < viaDiag ? calc : viaDiag;
+				}
+				column_step(x, eq, !(leftExists && pm[e] >= 0), calc);
+				if (first) { c = x; first = false; } else column_merge(c, x);
+			}
+			exists = exists0;
+			if (inPrev && c.before > pend0) { column_reenter(c, c.before - pend0); exists = true; }     // vertical re-entry (:1504-1509)
+		}
+		// ---- the node's columns ----
+		int nodeMin = INF;
+		int zero = zero0;
+		int above2 = ew_end2(pend0raw);
+		uint32_t endWord = 0;
+		for (uint32_t w = 0; w < len; w++)
+		{
+			if (w > 0)
+			{
+				const int base = g_base(g, firstCol + w);
+				const uint32_t peRaw = inPrev ? pend[(uint64_t)w * 64] : 0u;
+				const int pe = inPrev ? ew_end(peRaw) : INF;
+				const int z1 = zero + 1;
+				zero = z1 < pe ? z1 : pe;                                          // :1939-1944
+				const bool existsW = inPrev && pe == zero;
+				const bool aboveEq = aboveAlways || (!j0 && st.rawAbove == base);
+				int calc = c.before + 1;
+				if (existsW) { const int viaDiag = above2 + 1 - (aboveEq ? 1 : 0); calc = calc < viaDiag ? calc : viaDiag; }    // :1361-1370
+				column_step(c, eq_for(st, base), !exists, calc);
+				exists = existsW;
+				if (inPrev && calc > pe) { column_reenter(c, calc - pe); exists = true; }             // :1541-1546
+				above2 = ew_end2(peRaw);
+			}
+			const int end = col_end(c);
+			endWord = ((uint32_t)end << 3) | (exists ? 4u : 0u) | ((uint32_t)(c.vn >> 63) << 1) | (uint32_t)(c.vp >> 63);
+			rec_store<R>(m, st.rowBase + colBase + w, c, endWord);
+			m.endCur[(uint64_t)(colBase + w) * 64] = endWord;
+			nodeMin = end < nodeMin ? end : nodeMin;
+			if (end <= sliceMin) { sliceMin = end; minSlot = s; minOffset = w; }  // the LAST column attaining the minimum (:1551-1559, 2410-2418)
+		}
+		if (c.before != zero) { status = GA_ASSERTION; ord = -1; continue; }      // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
+		l.wr(LY::C_MIN + s, (uint32_t)nodeMin);
+		l.wr(LY::C_END + s, endWord);
+		ord--;
+	}
+	if (active)
+	{
+		st.sliceMin = sliceMin; st.minSlot = minSlot; st.minOffset = minOffset;
+		if (status != GA_OK) st.status = status;
+	}
+}
+
+// ---- the slice loop of one lane, cut at the points where the wave decides something together ---------------------
+template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m, LaneState& st, uint32_t jobIndex, bool hasJob)
+{
+	typedef Lay<N> LY;
+	st.job = jobIndex;
+	st.status = hasJob ? GA_OK : GA_NOT_RUN;
+	st.live = false;
+	st.pn = 0; st.cn = 0; st.prevMin = 0; st.totalCols = 0; st.rowBase = 0;
+	st.e0 = st.e1 = st.e2 = st.e3 = 0; st.rawAbove = 7;
+	st.sliceMin = 0; st.minSlot = 0; st.minOffset = 0;
+	st.nPushed = 0; st.nRun = 0; st.maxBandNodes = 0; st.kept = 0; st.nColumns = 0; st.rampUntil = 0; st.useRamp = false;
+	st.nRows = 0; st.numSlices = 0; st.seedNode = 0; st.eq = L.eq;
+	st.logCorrect = 0; st.logWrong = 0;
+	if (!hasJob) return;
+	const GaJob job = L.jobs[jobIndex];
+	st.nRows = job.n_rows;
+	st.numSlices = job.n_rows / W;
+	st.seedNode = job.seed_node;
+	st.eq = L.eq + (job.rows_off / W) * 5;
+	st.logCorrect = L.hmm->init_correct;
+	st.logWrong = L.hmm->init_wrong;
+	// the traceback asserts samplingFrequency > 1 (:906) for fewer than four slices: such reads take the ladder, which reports it
+	if (st.numSlices < 4 || st.numSlices > L.max_slices) { st.status = GA_PUNT; return; }
+	const uint32_t seedLen = g_rec(L.graph, job.seed_node)[2];
+	if (seedLen > L.cap_cols || seedLen > 0xffffu) { st.status = GA_CAP_COLS; return; }
+	// initial slice: the whole seed node at score 0 (GraphAligner.h:2945-2960)
+	m.lds.wr(LY::P_NODE, job.seed_node);
+	m.lds.wr(LY::P_END, 0u | 4u);
+	m.lds.wr(LY::P_PACK, 0);
+	for (uint32_t c = 0; c < seedLen; c++) m.endPrev[(uint64_t)c * 64] = 4u;       // score 0, scoreEndExists
+	st.pn = 1;
+	st.live = true;
+}
+
+// band of the next slice; returns with st.totalCols set (0 when the lane is not computing this slice)
+template <int N> GAL_FN void lane_band(const GaLanesLaunch& L, const LaneMem& m, LaneState& st, uint32_t slice)
+{
+	st.totalCols = 0;
+	if (!st.live) return;
+	if (slice >= st.numSlices) { st.live = false; return; }
+	// slice 0 always runs at the ramp width because rampUntil(0) >= slice(0) (:2603,2612)
+	st.useRamp = st.rampUntil >= slice;
+	const int bandwidth = st.useRamp ? L.ramp_bw : L.initial_bw;
+	const uint64_t* e = st.eq + (uint64_t)slice * 5;
+	st.e0 = e[0]; st.e1 = e[1]; st.e2 = e[2]; st.e3 = e[3];
+	const uint32_t meta = (uint32_t)e[4];
+	st.rawAbove = slice > 0 ? (int)((uint32_t)e[-1] & 7u) : 7;
+	int rc = project_band<N>(L.graph, m, st, bandwidth);
+	if (rc == GA_OK && st.totalCols > L.cap_cols) rc = GA_CAP_COLS;
+	if (rc == GA_OK) rc = band_order<N>(L.graph, m, st);
+	if (rc == GA_OK && (meta & 8u)) rc = GA_ASSERTION;                            // characterMatch default branch (:2104-2106)
+	if (rc != GA_OK) { st.status = rc; st.live = false; st.totalCols = 0; }
+}
+
+// after the fill: HMM step, stop test, bookkeeping, and the slice becomes the state (getSqrtSlices, :2571-2856)
+template <int N> GAL_FN void lane_end_slice(const GaLanesLaunch& L, LaneMem& m, LaneState& st, uint32_t slice)
+{
+	typedef Lay<N> LY;
+	if (!st.live) return;
+	const Lds& l = m.lds;
+	if (st.status != GA_OK) { st.live = false; return; }
+	if (st.sliceMin < st.prevMin) { st.status = GA_ASSERTION; st.live = false; return; }        // :2469
+	st.nRun++;
+	st.nColumns += st.totalCols;
+	st.maxBandNodes = st.maxBandNodes > (uint32_t)st.cn ? st.maxBandNodes : (uint32_t)st.cn;
+	// ---- HMM step (AlignmentCorrectnessEstimation.cpp:71-89): additions and comparisons only ----
+	const GaHmmTables& hmm = *L.hmm;
+	const int mism = st.sliceMin - st.prevMin;
+	if (mism > 64) { st.status = GA_ASSERTION; st.live = false; return; }
+	const double cc = st.logCorrect + hmm.c2c, fc = st.logWrong + hmm.f2c, cf = st.logCorrect + hmm.c2f, ff = st.logWrong + hmm.f2f;
+	const bool correctFromCorrect = cc >= fc;
+	const bool falseFromCorrect = cf >= ff;
+	const double newCorrect = (cc > fc ? cc : fc) + hmm.correct_mult[mism];
+	const double newWrong = (cf > ff ? cf : ff) + hmm.wrong_mult[mism];
+	const bool currentlyCorrect = newCorrect > newWrong;
+	if (!correctFromCorrect) { st.live = false; return; }                                         // :2640-2647 (this slice is not kept)
+	const bool rampPossible = L.ramp_bw > L.initial_bw;
+	if (!currentlyCorrect && st.rampUntil < slice && rampPossible) { st.status = GA_UNSUPPORTED_RAMP; st.live = false; return; }   // the redo (:2648-2719) is the ladder's
+	// the slice is kept: header and node list for the traceback
+	const int cn = st.cn;
+	uint32_t* h = m.hdr + (uint64_t)slice * kHdrWords * 64;
+	h[0] = (uint32_t)cn; h[64] = st.totalCols; h[128] = (uint32_t)st.sliceMin; h[192] = (uint32_t)st.minSlot; h[256] = st.minOffset;
+	h[320] = (uint32_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0));
+	h[384] = st.rowBase;
+	uint32_t* sn = m.snodes + (uint64_t)slice * 2 * N * 64;
+	for (int k = 0; k < cn; k++)
+	{
+		const uint32_t node = l.rd(LY::C_NODE + k), geo = l.rd(LY::C_GEO + k);
+		sn[(uint64_t)(2 * k) * 64] = node;
+		sn[(uint64_t)(2 * k + 1) * 64] = geo & 0xffffu;
+		// ... and the slice becomes the state the next one is computed from
+		l.wr(LY::P_NODE + k, node);
+		l.wr(LY::P_END + k, l.rd(LY::C_END + k));
+		const uint32_t rel = l.rd(LY::C_MIN + k) - (uint32_t)st.sliceMin;
+		if (rel > 0xffffu) { st.status = GA_PUNT; st.live = false; return; }
+		l.wr(LY::P_PACK + k, (geo & 0xffffu) | (rel << 16));
+	}
+	st.nPushed++;
+	st.logCorrect = newCorrect; st.logWrong = newWrong;
+	st.pn = cn;
+	st.prevMin = st.sliceMin;
+	uint32_t* t = m.endPrev; m.endPrev = m.endCur; m.endCur = t;
+}
+
+// ---- traceback (getTraceFromTable :894-957 with pickBacktracePredecessor :493-591) and the job's output ----------
+template <int N, int R> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& m, LaneState& st, bool hasJob)
+{
+	typedef Lay<N> LY;
+	if (!hasJob) return;
+	const GaDevGraph& g = L.graph;
+	const Lds& l = m.lds;
+	GaJobOut out;
+	out.status = st.status; out.score = 0x7fffffff; out.n_valid = 0; out.n_run = st.nRun; out.trace_len = 0; out.max_band_nodes = st.maxBandNodes;
+	out.n_columns = st.nColumns; out.trace_off = 0; out.start_node = 0; out.start_offset = 0; out.start_row = 0; out.reserved2 = 0;
+	for (int i = 0; i < 8; i++) out.stamps[i] = 0;
+	int status = st.status;
+	// ---- drop the wrongly aligned tail (removeWronglyAlignedEnd, :2554-2569) ----
+	uint32_t kept = st.nPushed;
+	if (status == GA_OK && kept > 0)
+	{
+		bool ok = (m.hdr[((uint64_t)(kept - 1) * kHdrWords + 5) * 64] & 1u) != 0;
+		while (!ok)
+		{
+			kept--;
+			if (kept == 0) break;
+			ok = (m.hdr[((uint64_t)(kept - 1) * kHdrWords + 5) * 64] & 2u) != 0;
+		}
+	}
+	out.n_valid = status == GA_OK ? kept : 0;
+	uint32_t len = 0;
+	if (status == GA_OK && kept > 0)
+	{
+		const int big = (int)st.nRows;                                            // getValueOrMax default = sequence.size()
+		uint32_t sIdx = kept - 1;
+		uint32_t nN = 0, pN = 0, curRow = 0, prvRow = 0;
+		int tCN = LY::T_CN, tCB = LY::T_CB, tPN = LY::T_PN, tPB = LY::T_PB;
+		auto loadTable = [&](int tn, int tb, uint32_t sl, uint32_t& count, uint32_t& rowBase) {
+			const uint32_t* h = m.hdr + (uint64_t)sl * kHdrWords * 64;
+			count = h[0];
+			rowBase = h[384];
+			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * 64;
+			for (uint32_t k = 0; k < count; k++) { l.wr(tn + (int)k, sn[(uint64_t)(2 * k) * 64]); l.wr(tb + (int)k, sn[(uint64_t)(2 * k + 1) * 64]); }
+		};
+		loadTable(tCN, tCB, sIdx, nN, curRow);
+		if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN, prvRow);
+		const uint32_t* h = m.hdr + (uint64_t)sIdx * kHdrWords * 64;
+		out.score = (int32_t)h[128];
+		uint32_t node = l.rd(tCN + (int)h[192]);
+		uint32_t offset = h[256];
+		uint32_t row = sIdx * W + (W - 1);
+		out.start_node = node; out.start_offset = offset; out.start_row = row;
+		uint64_t e[4];
+		auto loadEq = [&](uint32_t sl) { const uint64_t* q = st.eq + (uint64_t)sl * 5; e[0] = q[0]; e[1] = q[1]; e[2] = q[2]; e[3] = q[3]; };
+		loadEq(sIdx);
+		// cell value from the stored words (getValueOrMax, GraphAligner.h:2008-2017)
+		auto valueIn = [&](int tn, int tb, uint32_t count, uint32_t rowBase, uint32_t n, uint32_t off, int r) -> int {
+			const int sl = find_in(l, tn, (int)count, n);
+			if (sl < 0) return big;
+			Col c; uint32_t ew;
+			rec_load<R>(m, rowBase + l.rd(tb + sl) + off, c, ew);
+			return col_value(c.vp, c.vn, c.before, r);
+		};
+		uint32_t pack = 0;
+		while (true)
+		{
+			if (row == 0xffffffffu) break;                                          // reached the row before the first one
+			if (len + 4 >= L.cap_moves) { status = GA_CAP_TRACE; break; }
+			const int r = (int)(row - sIdx * W);
+			const int slot = find_in(l, tCN, (int)nN, node);
+			if (slot < 0) { status = GA_ASSERTION; break; }                        // assert(slice.scores.hasNode(nodeIndex)) (:498)
+			const uint32_t colRow = curRow + l.rd(tCB + slot) + offset;
+			Col c; uint32_t ew;
+			rec_load<R>(m, colRow, c, ew);
+			const int here = col_value(c.vp, c.vn, c.before, r);
+			if (row == 0 && node == st.seedNode && (here == 0 || here == 1)) { row = 0xffffffffu; continue; }     // free start (:500)
+			const uint32_t* rec = g_rec(g, node);
+			const uint64_t firstCol = ((uint64_t)rec[1] << 32) | rec[0];
+			const int base = g_base(g, firstCol + offset);
+			const bool match = ((e[base] >> r) & 1) != 0;
+			int res = 0, via = 0;
+			const uint32_t curNode = node, curOffset = offset;
+			auto decide = [&](int horizontal, int diagonal, uint32_t un, uint32_t uo) -> int {
+				if (horizontal < here - 1) return -1;
+				if (horizontal == here - 1) { node = un; offset = uo; return 1; }
+				if (match)
+				{
+					if (diagonal < here) return -1;
+					if (diagonal == here) { node = un; offset = uo; row = row - 1; return 2; }
+				}
+				else
+				{
+					if (diagonal < here - 1) return -1;
+					if (diagonal == here - 1) { node = un; offset = uo; row = row - 1; return 2; }
+				}
+				return 0;
+			};
+			// value one row up in column (n, o): this slice for r > 0, the slice above (its row 63) for r == 0, the all-zero seed slice before slice 0
+			auto valueUp = [&](uint32_t n, uint32_t o) -> int {
+				if (r > 0) return valueIn(tCN, tCB, nN, curRow, n, o, r - 1);
+				if (sIdx == 0) return n == st.seedNode ? 0 : big;
+				return valueIn(tPN, tPB, pN, prvRow, n, o, W - 1);
+			};
+			if (curOffset == 0)
+			{
+				const uint32_t inDeg = rec[3] & 0xffffu;
+				for (uint32_t k = 0; k < inDeg && res == 0; k++)
+				{
+					const uint32_t nb = inDeg <= 4 ? rec[8 + k] : g.in_nbr[g.in_off[curNode] + k];
+					const uint32_t mo = (inDeg <= 4 ? rec[12 + k] : g_rec(g, nb)[2]) - 1;
+					via = (int)k;
+					const int horizontal = valueIn(tCN, tCB, nN, curRow, nb, mo, r);
+					int diagonal = 0;
+					if (horizontal > here - 1) diagonal = valueUp(nb, mo);
+					res = decide(horizontal, diagonal, nb, mo);
+				}
+			}
+			else
+			{
+				Col lc; uint32_t lew;
+				rec_load<R>(m, colRow - 1, lc, lew);
+				const int horizontal = col_value(lc.vp, lc.vn, lc.before, r);
+				int diagonal = 0;
+				if (horizontal > here - 1) diagonal = r > 0 ? col_value(lc.vp, lc.vn, lc.before, r - 1) : valueUp(curNode, curOffset - 1);
+				res = decide(horizontal, diagonal, curNode, curOffset - 1);
+			}
+			if (res < 0) { status = GA_ASSERTION; break; }
+			if (res == 0)
+			{
+				const int up = r > 0 ? col_value(c.vp, c.vn, c.before, r - 1) : valueUp(curNode, curOffset);
+				if (up != here - 1) { status = GA_ASSERTION; break; }              // assert(false) (:588)
+				row = row - 1;
+				res = 3;
+			}
+			// put the move away (the step onto the row before the first one is not part of the trace, :949-950)
+			if (row != 0xffffffffu)
+			{
+				if (via > 62) { status = GA_CAP_TRACE; break; }
+				const uint32_t code = res == 1 ? GA_MOVE_LEFT : res == 2 ? GA_MOVE_DIAG : GA_MOVE_UP;
+				pack |= (code | (res == 3 ? 0u : ((uint32_t)via << 2))) << (8 * (len & 3));
+				if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * 64] = pack; pack = 0; }
+				len++;
+			}
+			if (res >= 2 && r == 0 && row != 0xffffffffu)
+			{
+				// stepped into the slice above
+				sIdx--;
+				int t = tCN; tCN = tPN; tPN = t;
+				t = tCB; tCB = tPB; tPB = t;
+				nN = pN; curRow = prvRow;
+				if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN, prvRow);
+				loadEq(sIdx);
+			}
+		}
+		if (len & 3) m.moves[(uint64_t)(len >> 2) * 64] = pack;
+		// hand the moves over: claim `len` bytes (rounded to words) of the pool and copy them
+		if (status == GA_OK)
+		{
+			const uint32_t words = (len + 3) / 4;
+#ifdef GA_EMULATE
+			const uint64_t at = *L.trace_top; *L.trace_top += (uint64_t)words * 4;
+#else
+			const uint64_t at = atomicAdd((unsigned long long*)L.trace_top, (unsigned long long)words * 4);
+#endif
+			if (at + (uint64_t)words * 4 > L.trace_pool_cap) status = GA_CAP_TRACE;
+			else
+			{
+				uint32_t* dst = (uint32_t*)(L.traces + at);
+				for (uint32_t k = 0; k < words; k++) dst[k] = m.moves[(uint64_t)k * 64];
+				out.trace_off = at;
+				out.trace_len = len;
+			}
+		}
+	}
+	out.status = status;
+	if (status != GA_OK) { out.n_valid = 0; out.score = 0x7fffffff; out.trace_len = 0; }
+	L.outs[st.job] = out;
+}
+
+}  // namespace gal

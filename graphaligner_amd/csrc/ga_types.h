@@ -15,6 +15,7 @@ enum GaStatus : int32_t {
 	GA_CAP_HEAP = 14,          // band-projection heap exhausted
 	GA_UNSUPPORTED_CYCLE = 20, // band subgraph has a cycle (iterative row confirmation, GraphAligner.h:2362-2397, not built on device)
 	GA_UNSUPPORTED_RAMP = 21,  // the ramp-redo path (GraphAligner.h:2648-2719) would have been taken
+	GA_PUNT = 22,              // the lanes = reads kernel declines the job (short read, node degree > 4, ...): the wave-per-read ladder runs it
 	GA_NOT_RUN = 99,
 };
 

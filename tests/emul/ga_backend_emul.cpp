@@ -14,6 +14,9 @@
 
 #include "../../graphaligner_amd/csrc/ga_backend.h"
 #include "../../graphaligner_amd/csrc/ga_kernel.h"
+#include "../../graphaligner_amd/csrc/ga_lanes.h"
+#include <cstdlib>
+#include <cstdio>
 
 namespace {
 
@@ -29,9 +32,11 @@ struct EmulBatch : GaBackendBatch
 {
 	EmulGraph* g;
 	std::vector<uint8_t> rows;
+	std::vector<uint64_t> eq;
 	std::vector<GaJob> jobs;
 	GaRunConfig cfg;
 	std::vector<GaJobOut> outs;
+	uint64_t lanesDone = 0;
 	std::vector<uint8_t> pool;
 	uint64_t poolTop = 0;
 	uint64_t retried = 0;
@@ -53,6 +58,63 @@ struct EmulBatch : GaBackendBatch
 		gak::run_job<MAXN, GENERAL>(L, *ws, slot, job);
 	}
 
+	// the lanes = reads program (ga_lanes.h): a wave's 64 lanes are run one after the other through each phase; the points
+	// where the real wave decides something together (any lane still live, the slice's row range) sit between the phases
+	template <int N, int R> void runLanesGroup(const std::vector<uint32_t>& group, uint32_t capCols, uint32_t capRows, uint32_t capMoves)
+	{
+		using namespace gal;
+		GaLanesLaunch L;
+		memset(&L, 0, sizeof(L));
+		L.graph = g->dev; L.hmm = &g->hmm; L.eq = eq.data(); L.jobs = jobs.data(); L.outs = outs.data();
+		L.n_jobs = (uint32_t)jobs.size(); L.lanes_per_wave = 64;
+		L.traces = pool.data(); L.trace_top = &poolTop; L.trace_pool_cap = pool.size();
+		L.cap_cols = capCols; L.cap_rows = capRows; L.max_slices = cfg.max_slices; L.cap_moves = capMoves;
+		L.initial_bw = cfg.initial_bw; L.ramp_bw = cfg.ramp_bw;
+		const WaveLayout lay = wave_layout<N>(capCols, capRows, cfg.max_slices, capMoves);
+		std::vector<uint8_t> scratch(lay.bytes + 256);
+		std::vector<uint32_t> lds((size_t)Lay<N>::WORDS * 64);
+		std::vector<LaneMem> mem(64);
+		std::vector<LaneState> st(64);
+		for (int lane = 0; lane < 64; lane++)
+		{
+			LaneMem& m = mem[lane];
+			m.lane = lane;
+			m.lds.base = lds.data() + lane; m.lds.lw = 64;
+			m.endPrev = (uint32_t*)(scratch.data() + lay.endA) + lane;
+			m.endCur = (uint32_t*)(scratch.data() + lay.endB) + lane;
+			m.hdr = (uint32_t*)(scratch.data() + lay.hdr) + lane;
+			m.snodes = (uint32_t*)(scratch.data() + lay.snodes) + lane;
+			m.moves = (uint32_t*)(scratch.data() + lay.moves) + lane;
+			m.arena = scratch.data() + lay.arena;
+			const bool has = lane < (int)group.size();
+			lane_begin<N>(L, m, st[lane], has ? group[lane] : 0, has);
+		}
+		uint32_t rowTop = 0;
+		for (uint32_t slice = 0; ; slice++)
+		{
+			bool any = false;
+			uint32_t maxCols = 0;
+			for (int lane = 0; lane < 64; lane++)
+			{
+				lane_band<N>(L, mem[lane], st[lane], slice);
+				any = any || st[lane].live;
+				maxCols = std::max(maxCols, st[lane].totalCols);
+			}
+			if (!any) break;
+			const bool fits = rowTop + maxCols <= L.cap_rows;
+			for (int lane = 0; lane < 64; lane++)
+			{
+				if (!fits && st[lane].live) { st[lane].status = GA_CAP_ARENA; st[lane].live = false; }
+				st[lane].rowBase = rowTop;
+			}
+			if (!fits) break;
+			rowTop += maxCols;
+			for (int lane = 0; lane < 64; lane++) fill_slice<N, R>(L.graph, mem[lane], st[lane], slice, st[lane].live);
+			for (int lane = 0; lane < 64; lane++) lane_end_slice<N>(L, mem[lane], st[lane], slice);
+		}
+		for (int lane = 0; lane < 64; lane++) lane_finish<N, R>(L, mem[lane], st[lane], lane < (int)group.size());
+	}
+
 	int run() override
 	{
 		outs.assign(jobs.size(), GaJobOut{});
@@ -61,9 +123,38 @@ struct EmulBatch : GaBackendBatch
 		pool.assign(totalRows * 3 + 4096 * jobs.size() + 64, 0);
 		poolTop = 0;
 		retried = 0;
+		// first pass: the lanes = reads program, groups of 64 jobs (longest first, as the device queue hands them out), with
+		// deliberately small capacities; what it declines or cannot hold climbs the wave-per-read ladder below
+		const bool lanesFirst = !(getenv("GA_EMUL_NO_LANES") && atoi(getenv("GA_EMUL_NO_LANES")));
+		if (lanesFirst)
+		{
+			// jobs a lanes variant cannot hold (band wider than its LDS tables) move on to the next one, regrouped
+			std::vector<uint32_t> order(jobs.size());
+			for (uint32_t i = 0; i < jobs.size(); i++) order[i] = i;
+			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n_rows > jobs[b].n_rows; });
+			for (int pass = 0; pass < 3 && !order.empty(); pass++)
+			{
+				for (size_t at = 0; at < order.size(); at += 64)
+				{
+					std::vector<uint32_t> group(order.begin() + at, order.begin() + std::min(order.size(), at + 64));
+					const uint32_t maxRows = jobs[group[0]].n_rows;
+					const uint32_t capRows = (maxRows / 64) * (pass == 0 ? 600 : 2500) + 64, capMoves = maxRows * (pass == 0 ? 2 : 3) + 512;
+					if (pass == 0) { if ((at / 64) % 2 == 0) runLanesGroup<16, 2>(group, 2048, capRows, capMoves); else runLanesGroup<16, 1>(group, 2048, capRows, capMoves); }
+					else if (pass == 1) runLanesGroup<32, 4>(group, 4096, capRows, capMoves);
+					else runLanesGroup<64, 8>(group, 8192, capRows, capMoves);
+				}
+				std::vector<uint32_t> again;
+				for (uint32_t j : order) if (outs[j].status == GA_CAP_NODES || outs[j].status == GA_CAP_HEAP || outs[j].status == GA_CAP_COLS || outs[j].status == GA_CAP_ARENA || outs[j].status == GA_CAP_TRACE) again.push_back(j);
+				order.swap(again);
+			}
+		}
+		lanesDone = 0;
+		if (getenv("GA_EMUL_DEBUG") && lanesFirst) { int hist[100] = {0}; for (auto& o : outs) hist[o.status < 100 ? o.status : 99]++; fprintf(stderr, "emul: lanes statuses:"); for (int i = 0; i < 100; i++) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]); fprintf(stderr, "\n"); }
 		for (uint32_t j = 0; j < jobs.size(); j++)
 		{
 			uint32_t slices = jobs[j].n_rows / 64;
+			auto finalStatus = [](int s) { return s == GA_OK || s == GA_ASSERTION || s == GA_UNSUPPORTED_BAND || s == GA_BAD_SEED; };
+			if (lanesFirst && finalStatus(outs[j].status)) { lanesDone++; continue; }
 			// deliberately small first-try capacities so the retry ladder is exercised too
 			runOne<32, false>(j, 2048, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 40 + 5 * 700), jobs[j].n_rows * 2 + 512);
 			auto capacity = [](int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; };
@@ -74,6 +165,7 @@ struct EmulBatch : GaBackendBatch
 			if (capacity(outs[j].status) || general(outs[j].status))
 				runOne<256, true>(j, 200000, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 256 + 5 * 20000) * 3, jobs[j].n_rows * 8 + 4096);
 		}
+		if (getenv("GA_EMUL_DEBUG")) { int hist[100] = {0}; for (auto& o : outs) hist[o.status < 100 ? o.status : 99]++; fprintf(stderr, "emul: %zu jobs, %llu finished by the lanes program, %llu retried; final statuses:", jobs.size(), (unsigned long long)lanesDone, (unsigned long long)retried); for (int i = 0; i < 100; i++) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]); fprintf(stderr, "\n"); }
 		return 0;
 	}
 	int fetch(std::vector<GaJobOut>& o, std::vector<uint8_t>& traces) override
@@ -106,11 +198,12 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, const std::vector<uint8_t>& rows, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
 {
 	EmulBatch* b = new EmulBatch();
 	b->g = static_cast<EmulGraph*>(g);
 	b->rows = rows;
+	b->eq = eq;
 	b->jobs = jobs;
 	b->cfg = cfg;
 	*status = 0;
