@@ -204,8 +204,8 @@ def main():
                 pc.compare_read(dict(some[i], trace=np.zeros((0, 7), dtype=np.int64)), dict(og.align(reads[i], [seeds[i]], args.bandwidth), trace=np.zeros((0, 7), dtype=np.int64)), "bench read %d" % i)
         out["detail"]["oracle_spot_check_reads"] = min(args.check, n)
     if args.stamps:
-        names = ["misc", "project_band", "topology", "order", "fill", "traceback", "trace_copy", "-"]
-        tot = float(sum(st["stamps"])) or 1.0
+        names = ["end_slice", "band+order", "trace_fast(in traceback)", "trace_general(in traceback)", "fill", "traceback", "trace_handover(in traceback)", "-"]
+        tot = float(st["stamps"][0] + st["stamps"][1] + st["stamps"][4] + st["stamps"][5]) or 1.0
         out["detail"]["phase_share"] = {n: round(v / tot, 4) for n, v in zip(names, st["stamps"])}
         out["detail"]["cycles_per_job"] = round(tot / max(1, st["n_jobs"]))
     print(json.dumps(out), flush=True)

@@ -52,7 +52,8 @@ class GaResults(C.Structure):
 class GaBatchStats(C.Structure):
     _fields_ = [("n_jobs", C.c_uint64), ("column_updates", C.c_uint64), ("slices", C.c_uint64), ("jobs_retried", C.c_uint64),
                 ("kernel_ms", C.c_double), ("prep_kernel_ms", C.c_double), ("slots", C.c_uint32), ("waves_per_cu", C.c_uint32),
-                ("scratch_bytes", C.c_uint64), ("stamps", C.c_uint64 * 8)]
+                ("scratch_bytes", C.c_uint64), ("stamps", C.c_uint64 * 8), ("main_kernel_ms", C.c_double), ("main_variant", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class GaNamedSeed(C.Structure):

@@ -50,7 +50,9 @@ struct GaRunConfig
 
 struct GaRunStats
 {
-	double kernel_ms = 0;
+	double kernel_ms = 0;               // all passes of the last run
+	double main_ms = 0;                 // the first pass (lanes = reads kernel)
+	int main_variant = 0;               // its template arguments: band nodes per lane * 1000 + record block * 10 + (1 when 32 lanes per wave)
 	uint32_t slots = 0, waves_per_cu = 0;
 	uint64_t scratch_bytes = 0;
 	uint64_t jobs_retried = 0;

@@ -14,6 +14,7 @@
 #include "../../include/graphaligner_amd.h"
 #include "ga_backend.h"
 #include "ga_kernel.h"
+#include "ga_lanes.h"
 
 namespace {
 
@@ -68,6 +69,61 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GA_WAVE
 	}
 }
 
+// ---- lanes = reads (ga_lanes.h): every lane owns one job, the wave's lanes advance slice by slice together -----------
+// N band nodes per lane in LDS (10 N words per lane), slice records in blocks of R columns per lane, LW = lane stride of
+// the LDS tables = how many lanes of a wave carry jobs.
+template <int N, int LW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) ga_lanes_kernel(gal::GaLanesLaunch L)
+{
+	using namespace gal;
+	__shared__ uint32_t lds[Lay<N>::WORDS * LW + 64 * kStageWords64 * 2];
+	const int lane = (int)threadIdx.x;
+	const WaveLayout lay = wave_layout<N>(L.cap_cols, L.cap_rows, L.max_slices, L.cap_moves);
+	uint8_t* base = L.scratch + (uint64_t)blockIdx.x * L.wave_bytes;
+	while (true)
+	{
+		const uint32_t grp = gaw::wave_atomic_add(L.next_group, 1u);
+		const uint64_t first = (uint64_t)grp * L.lanes_per_wave;
+		if (first >= L.n_jobs) break;                      // every wave reaches this exit once the queue is drained
+		const bool hasJob = lane < (int)L.lanes_per_wave && lane < LW && first + (uint32_t)lane < L.n_jobs;
+		const uint32_t jobIndex = hasJob ? (L.job_list ? L.job_list[first + (uint32_t)lane] : (uint32_t)(first + (uint32_t)lane)) : 0u;
+		LaneMem m;
+		m.lane = lane;
+		m.lds.base = lds + (lane < LW ? lane : 0);
+		m.lds.lw = LW;
+		m.stage = (uint64_t*)(lds + Lay<N>::WORDS * LW);
+		m.endPrev = (uint32_t*)(base + lay.endA) + lane;
+		m.endCur = (uint32_t*)(base + lay.endB) + lane;
+		m.hdr = (uint32_t*)(base + lay.hdr) + lane;
+		m.snodes = (uint32_t*)(base + lay.snodes) + lane;
+		m.moves = (uint32_t*)(base + lay.moves) + lane;
+		m.arena = base + lay.arena;
+		LaneState st;
+		uint64_t tA = gaw::stamp(), tB, acc[4] = {0, 0, 0, 0};
+#define GAL_LAP(i) do { tB = gaw::stamp(); acc[i] += tB - tA; tA = tB; } while (0)
+		lane_begin<N>(L, m, st, jobIndex, hasJob);
+		uint32_t rowTop = 0;                               // wave-uniform: one arena row per step of the wave
+		for (uint32_t slice = 0; ; slice++)
+		{
+			lane_band<N>(L, m, st, slice);
+			GAL_LAP(0);
+			if (!__ballot(st.live)) break;
+			fill_slice<N, 8>(L.graph, m, st, slice, st.live, rowTop, L.cap_rows, L.cap_cols);
+			GAL_LAP(1);
+			lane_end_slice<N>(L, m, st, slice);
+			GAL_LAP(2);
+		}
+		lane_finish<N>(L, m, st, hasJob);
+		GAL_LAP(3);
+#undef GAL_LAP
+#ifdef GA_STAMPS
+		// diagnostic build: the wave's cycles per phase, booked on its first job (names in bench.py)
+		if (hasJob && lane == 0) { GaJobOut* o = L.outs + st.job; o->stamps[1] = acc[0]; o->stamps[4] = acc[1]; o->stamps[0] = acc[2]; o->stamps[5] = acc[3]; o->stamps[2] = st.laps[0]; o->stamps[3] = st.laps[1]; o->stamps[6] = st.laps[2]; }
+#endif
+		__syncthreads();
+	}
+}
+
 struct DevGraph : GaBackendGraph
 {
 	int device = 0;
@@ -75,7 +131,26 @@ struct DevGraph : GaBackendGraph
 	GaHmmTables* hmm = nullptr;
 	std::vector<void*> allocs;
 	int cus = 0;
-	~DevGraph() override { hipSetDevice(device); for (void* p : allocs) hipFree(p); }
+	uint64_t totalBp = 0;
+	// scratch pool owned by the graph: batches reuse it instead of allocating tens of GB each
+	uint8_t* pool = nullptr;
+	size_t poolBytes = 0;
+	bool poolBusy = false;
+	~DevGraph() override { hipSetDevice(device); for (void* p : allocs) hipFree(p); if (pool) hipFree(pool); }
+	uint8_t* takePool(size_t bytes)
+	{
+		if (poolBusy) return nullptr;
+		if (bytes > poolBytes)
+		{
+			if (pool) hipFree(pool);
+			pool = nullptr; poolBytes = 0;
+			if (hipMalloc((void**)&pool, bytes) != hipSuccess) { pool = nullptr; return nullptr; }
+			poolBytes = bytes;
+		}
+		poolBusy = true;
+		return pool;
+	}
+	void givePool() { poolBusy = false; }
 	template <typename T> int put(const std::vector<T>& v, const T** out)
 	{
 		void* p = nullptr;
@@ -91,29 +166,27 @@ struct DevBatch : GaBackendBatch
 {
 	DevGraph* g = nullptr;
 	hipStream_t stream = nullptr;
-	hipEvent_t evStart = nullptr, evStop = nullptr;
+	hipEvent_t evA = nullptr, evB = nullptr;
 	std::vector<void*> allocs;
 	std::vector<GaJob> jobs;
 	GaRunConfig cfg;
-	GaLaunch L;                 // main launch
-	uint32_t slots = 0, wavesPerCu = 0;
-	bool narrow = true;         // first pass with the 32-node variant (more waves per CU); misses go to the 256-node variant
+	GaLaunch L;                 // what every pass shares (graph, reads, jobs, outputs, trace pool); scratch geometry is set per pass
+	const uint64_t* dEq = nullptr;
+	uint32_t* dList = nullptr;  // job list of the current pass
+	size_t dListCap = 0;
 	std::vector<GaJobOut> outs;
-	std::vector<uint32_t> orderHost;   // job order of the main launch (longest first) when lengths differ
+	std::vector<uint32_t> orderHost;   // all jobs, longest first (the device queues hand them out in this order)
 	GaRunStats st;
-	// retry pass (wide variant), built lazily
-	uint8_t* retryScratch = nullptr;
-	uint32_t* retryList = nullptr;
-	size_t retryScratchBytes = 0;
+	uint8_t* privateScratch = nullptr; // only when the graph's pool is taken by another batch
+	size_t privateBytes = 0;
 
 	~DevBatch() override
 	{
 		hipSetDevice(g->device);
 		for (void* p : allocs) hipFree(p);
-		if (retryScratch) hipFree(retryScratch);
-		if (retryList) hipFree(retryList);
-		if (evStart) hipEventDestroy(evStart);
-		if (evStop) hipEventDestroy(evStop);
+		if (privateScratch) hipFree(privateScratch);
+		if (evA) hipEventDestroy(evA);
+		if (evB) hipEventDestroy(evB);
 		if (stream) hipStreamDestroy(stream);
 	}
 	template <typename T> int alloc(T** out, size_t count)
@@ -125,12 +198,12 @@ struct DevBatch : GaBackendBatch
 		return 0;
 	}
 
-	int init(const std::vector<uint8_t>& rows, const std::vector<GaJob>& jobsIn)
+	int init(const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobsIn)
 	{
 		HIP_OK(hipSetDevice(g->device));
 		HIP_OK(hipStreamCreate(&stream));
-		HIP_OK(hipEventCreate(&evStart));
-		HIP_OK(hipEventCreate(&evStop));
+		HIP_OK(hipEventCreate(&evA));
+		HIP_OK(hipEventCreate(&evB));
 		jobs = jobsIn;
 		memset(&L, 0, sizeof(L));
 		L.graph = g->g;
@@ -139,26 +212,23 @@ struct DevBatch : GaBackendBatch
 		L.initial_bw = cfg.initial_bw;
 		L.ramp_bw = cfg.ramp_bw;
 		L.max_slices = std::max<uint32_t>(cfg.max_slices, 1);
-		uint8_t* dRows; GaJob* dJobs;
+		uint8_t* dRows; GaJob* dJobs; uint64_t* eqDev;
 		if (alloc(&dRows, rows.size())) return GA_E_DEVICE;
+		if (alloc(&eqDev, eq.size())) return GA_E_DEVICE;
 		if (alloc(&dJobs, jobs.size())) return GA_E_DEVICE;
 		HIP_OK(hipMemcpyAsync(dRows, rows.data(), rows.size(), hipMemcpyHostToDevice, stream));
+		HIP_OK(hipMemcpyAsync(eqDev, eq.data(), eq.size() * 8, hipMemcpyHostToDevice, stream));
 		HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GaJob), hipMemcpyHostToDevice, stream));
 		L.rows = dRows;
 		L.jobs = dJobs;
-		// the device queue hands jobs out longest first: the short ones fill the tail of the launch
-		bool uniform = true;
-		for (auto& j : jobs) if (j.n_rows != jobs[0].n_rows) { uniform = false; break; }
-		if (!uniform)
-		{
-			orderHost.resize(jobs.size());
-			for (uint32_t i = 0; i < jobs.size(); i++) orderHost[i] = i;
-			std::stable_sort(orderHost.begin(), orderHost.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n_rows > jobs[b].n_rows; });
-			uint32_t* dOrder;
-			if (alloc(&dOrder, orderHost.size())) return GA_E_DEVICE;
-			HIP_OK(hipMemcpyAsync(dOrder, orderHost.data(), orderHost.size() * 4, hipMemcpyHostToDevice, stream));
-			L.job_list = dOrder;
-		}
+		dEq = eqDev;
+		// the device queues hand jobs out longest first: the short ones fill the tail of a launch, and the 64 jobs a lanes = reads
+		// wave carries together have similar lengths
+		orderHost.resize(jobs.size());
+		for (uint32_t i = 0; i < jobs.size(); i++) orderHost[i] = i;
+		std::stable_sort(orderHost.begin(), orderHost.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n_rows > jobs[b].n_rows; });
+		dListCap = std::max<size_t>(jobs.size(), 1);
+		if (alloc(&dList, dListCap)) return GA_E_DEVICE;
 		if (alloc(&L.outs, jobs.size())) return GA_E_DEVICE;
 		if (alloc(&L.next_job, 4)) return GA_E_DEVICE;
 		if (alloc(&L.trace_top, 2)) return GA_E_DEVICE;
@@ -166,114 +236,180 @@ struct DevBatch : GaBackendBatch
 		for (auto& j : jobs) totalRows += j.n_rows;
 		L.trace_pool_cap = ((totalRows + totalRows / 2 + 256ull * jobs.size() + 4096) + 3) & ~3ull;
 		if (alloc(&L.traces, L.trace_pool_cap)) return GA_E_DEVICE;
-		// slot geometry: bands of ~300-700 columns are the rule (b = 35 on variation graphs);
-		// anything wider fails with a capacity status and is rerun by the wide variant
-		L.cap_cols = 4096;
-		L.trace_cap = cfg.max_rows * 2 + 1024;
-		L.arena_words = 64 + (uint64_t)L.max_slices * (gak::kSliceHdrWords + 3 * 64 + 5 * 800);
-		SlotLayout lay = slotLayout(L.cap_cols, L.max_slices, L.arena_words, L.trace_cap);
-		L.slot_bytes = lay.bytes;
-		size_t freeB = 0, totalB = 0;
-		HIP_OK(hipMemGetInfo(&freeB, &totalB));
-		wavesPerCu = getenv("GA_WAVES_PER_CU") ? (uint32_t)atoi(getenv("GA_WAVES_PER_CU")) : 24;
-		narrow = !(getenv("GA_NARROW") && atoi(getenv("GA_NARROW")) == 0);
-		uint64_t want = (uint64_t)g->cus * wavesPerCu;
-		uint64_t fit = (uint64_t)(freeB * 0.8) / std::max<uint64_t>(lay.bytes, 1);
-		slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(want, fit), std::max<size_t>(jobs.size(), 1)));
-		// (jobs are pulled from a device queue, so the slots need no balancing by hand; a few more workgroups than fit at once
-		// start as the first ones drain the queue and even out the tail)
-		if (alloc(&L.scratch, (size_t)slots * lay.bytes)) return GA_E_DEVICE;
-		st.slots = slots;
-		st.waves_per_cu = wavesPerCu;
-		st.scratch_bytes = (uint64_t)slots * lay.bytes;
 		HIP_OK(hipStreamSynchronize(stream));
 		return 0;
+	}
+
+	// scratch for one pass: the graph's pool, or a private allocation while another batch holds the pool
+	uint8_t* takeScratch(size_t bytes, bool& fromPool)
+	{
+		uint8_t* p = g->takePool(bytes);
+		fromPool = p != nullptr;
+		if (p) return p;
+		if (bytes > privateBytes)
+		{
+			if (privateScratch) hipFree(privateScratch);
+			privateScratch = nullptr; privateBytes = 0;
+			if (hipMalloc((void**)&privateScratch, bytes) != hipSuccess) { privateScratch = nullptr; return nullptr; }
+			privateBytes = bytes;
+		}
+		return privateScratch;
+	}
+	size_t scratchBudget() const
+	{
+		size_t freeB = 0, totalB = 0;
+		if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 0;
+		return (size_t)((freeB + (g->poolBusy ? privateBytes : g->poolBytes)) * 0.85);
+	}
+	int uploadList(const std::vector<uint32_t>& list)
+	{
+		HIP_OK(hipMemcpyAsync(dList, list.data(), list.size() * 4, hipMemcpyHostToDevice, stream));
+		return 0;
+	}
+	int afterPass(float& ms)
+	{
+		HIP_OK(hipGetLastError());
+		HIP_OK(hipEventRecord(evB, stream));
+		HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipStreamSynchronize(stream));
+		HIP_OK(hipEventElapsedTime(&ms, evA, evB));
+		st.kernel_ms += ms;
+		return 0;
+	}
+
+	static bool isCapacity(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP || s == GA_PUNT || s == GA_NOT_RUN; }
+	// bands with cycles and ramp redos: only the general wave-per-read variants carry those paths
+	static bool needsGeneral(int s) { return s == GA_UNSUPPORTED_CYCLE || s == GA_UNSUPPORTED_RAMP; }
+	// what a lanes = reads variant with larger tables can still take
+	static bool widerLanes(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; }
+
+	// one launch of the lanes = reads kernel over `list` (job indices, longest first)
+	template <int N, int LW> int lanesPass(const std::vector<uint32_t>& list, uint32_t rowsPerSlice, bool first)
+	{
+		if (list.empty()) return 0;
+		gal::GaLanesLaunch P;
+		memset(&P, 0, sizeof(P));
+		P.graph = L.graph; P.hmm = L.hmm; P.eq = dEq; P.jobs = L.jobs; P.outs = L.outs;
+		P.job_list = dList; P.n_jobs = (uint32_t)list.size();
+		P.lanes_per_wave = LW;
+		P.next_group = L.next_job;
+		P.traces = L.traces; P.trace_top = L.trace_top; P.trace_pool_cap = L.trace_pool_cap;
+		P.initial_bw = L.initial_bw; P.ramp_bw = L.ramp_bw;
+		uint32_t maxRows = 0;
+		for (uint32_t i : list) maxRows = std::max(maxRows, jobs[i].n_rows);
+		P.max_slices = std::max<uint32_t>(maxRows / 64, 1);
+		P.cap_cols = std::min<uint32_t>(N * 256u, 0xff00u);
+		P.cap_rows = P.max_slices * rowsPerSlice + 64;
+		P.cap_moves = maxRows * 2 + 1024;
+		const gal::WaveLayout lay = gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves);
+		P.wave_bytes = lay.bytes;
+		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + 64 * gal::kStageWords64 * 8;
+		const uint32_t wavesPerCu = std::max<uint32_t>(1, std::min<uint32_t>(8, 163840u / ldsBytes));
+		const uint64_t groups = (list.size() + LW - 1) / LW;
+		const uint64_t fit = scratchBudget() / std::max<uint64_t>(lay.bytes, 1);
+		const uint32_t waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * wavesPerCu, fit), groups));
+		bool fromPool = false;
+		uint8_t* scratch = takeScratch((size_t)waves * lay.bytes, fromPool);
+		if (!scratch) return 0;                            // no memory for this variant: the jobs keep their status and climb on
+		P.scratch = scratch;
+		int rc = uploadList(list);
+		if (!rc)
+		{
+			hipMemsetAsync(L.next_job, 0, 16, stream);
+			hipEventRecord(evA, stream);
+			hipLaunchKernelGGL((ga_lanes_kernel<N, LW>), dim3(waves), dim3(64), 0, stream, P);
+			float ms = 0;
+			rc = afterPass(ms);
+			if (first) { st.main_ms = ms; st.main_variant = N * 1000 + 80 + (LW == 64 ? 0 : 1); st.slots = waves; st.waves_per_cu = wavesPerCu; st.scratch_bytes = (uint64_t)waves * lay.bytes; }
+			if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: lanes pass <%d,%d>: %zu jobs on %u waves (%.1f GB scratch), %.2f ms\n", N, LW, list.size(), waves, waves * (double)lay.bytes / 1e9, ms);
+		}
+		if (fromPool) g->givePool();
+		return rc;
+	}
+
+	template <int MAXN, bool GENERAL> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry, bool takeCapacity, bool takeGeneral)
+	{
+		std::vector<uint32_t> again;
+		for (uint32_t i : orderHost) if ((takeCapacity && isCapacity(outs[i].status)) || (takeGeneral && needsGeneral(outs[i].status))) again.push_back(i);
+		if (again.empty()) return 0;
+		st.jobs_retried += again.size();
+		GaLaunch Rl = L;
+		uint32_t maxRows = 0;
+		for (uint32_t i : again) maxRows = std::max(maxRows, jobs[i].n_rows);
+		Rl.cap_cols = capCols;
+		Rl.trace_cap = maxRows * traceMul + 4096;
+		Rl.max_slices = std::max<uint32_t>(maxRows / 64, 1);
+		Rl.arena_words = 64 + (uint64_t)(maxRows / 64) * (gak::kSliceHdrWords + arenaWordsPerSlice);
+		SlotLayout lay = slotLayout(Rl.cap_cols, Rl.max_slices, Rl.arena_words, Rl.trace_cap);
+		Rl.slot_bytes = lay.bytes;
+		const uint64_t fit = scratchBudget() / lay.bytes;
+		uint32_t rslots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * wavesPerCuRetry, fit), again.size()));
+		bool fromPool = false;
+		uint8_t* scratch = takeScratch((size_t)rslots * lay.bytes, fromPool);
+		if (!scratch) return 0;                            // the affected jobs keep their capacity status
+		Rl.scratch = scratch;
+		Rl.job_list = dList;
+		Rl.n_jobs = (uint32_t)again.size();
+		int rc = uploadList(again);
+		if (!rc)
+		{
+			hipMemsetAsync(Rl.next_job, 0, 16, stream);
+			hipEventRecord(evA, stream);
+			hipLaunchKernelGGL((ga_extend_kernel<MAXN, GENERAL>), dim3(rslots), dim3(64), 0, stream, Rl);
+			float ms = 0;
+			rc = afterPass(ms);
+			if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: wave-per-read pass <%d,%d>: %zu jobs on %u slots, %.2f ms\n", MAXN, (int)GENERAL, again.size(), rslots, ms);
+		}
+		if (fromPool) g->givePool();
+		return rc;
 	}
 
 	int run() override
 	{
 		HIP_OK(hipSetDevice(g->device));
-		if (jobs.empty()) { outs.clear(); return 0; }
-		HIP_OK(hipMemsetAsync(L.next_job, 0, 16, stream));
+		st = GaRunStats();
+		outs.assign(jobs.size(), GaJobOut{});
+		if (jobs.empty()) return 0;
+		for (auto& o : outs) o.status = GA_NOT_RUN;
+		HIP_OK(hipMemcpyAsync(L.outs, outs.data(), outs.size() * sizeof(GaJobOut), hipMemcpyHostToDevice, stream));
 		HIP_OK(hipMemsetAsync(L.trace_top, 0, 16, stream));
-		HIP_OK(hipEventRecord(evStart, stream));
-		if (narrow) hipLaunchKernelGGL((ga_extend_kernel<32, false>), dim3(slots), dim3(64), 0, stream, L);
-		else hipLaunchKernelGGL((ga_extend_kernel<64, false>), dim3(slots), dim3(64), 0, stream, L);
-		HIP_OK(hipGetLastError());
-		HIP_OK(hipEventRecord(evStop, stream));
-		outs.resize(jobs.size());
-		HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));
-		HIP_OK(hipStreamSynchronize(stream));
-		float ms = 0;
-		HIP_OK(hipEventElapsedTime(&ms, evStart, evStop));
-		st.kernel_ms = ms;
-		if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: main pass: %zu jobs on %u slots, %.2f ms\n", jobs.size(), slots, ms);
-		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
-		// ---- what the lean variant could not finish climbs a ladder: 64 band nodes in LDS; then the general variants, which
-		// also carry the paths for bands with cycles and for ramp redos; last 256 band nodes with large buffers ----
+		// ---- first the lanes = reads kernel: one job per lane.  Its LDS tables hold 16, 32 or 64 band nodes per lane (4, 2, 1
+		// waves per CU); the starting size follows the graph's mean node length, and jobs a size cannot hold move to the next ----
+		const bool useLanes = !(getenv("GA_LANES") && atoi(getenv("GA_LANES")) == 0);
+		const int half = getenv("GA_LANES_PER_WAVE") && atoi(getenv("GA_LANES_PER_WAVE")) == 32;
+		int rc = 0;
+		if (useLanes)
+		{
+			const double meanNode = g->g.n_nodes > 2 ? (double)g->totalBp / (double)(g->g.n_nodes - 2) : 64.0;
+			int startN = meanNode >= 40 ? 0 : meanNode >= 14 ? 1 : 2;
+			if (getenv("GA_LANES_N")) startN = atoi(getenv("GA_LANES_N"));
+			std::vector<uint32_t> list = orderHost;
+			bool first = true;
+			for (int n = startN; n <= 2 && !list.empty() && !rc; n++)
+			{
+				// later sizes are only worth a launch of their own for enough jobs to fill waves; stragglers take the wave-per-read ladder
+				if (!first && list.size() < 512) break;
+				// (10 / 24 / 56 band nodes per lane = 4 / 2 / 1 waves per CU next to the 12.8 KB block image)
+				if (n == 0) rc = half ? lanesPass<10, 32>(list, 400, first) : lanesPass<10, 64>(list, 400, first);
+				else if (n == 1) rc = lanesPass<24, 64>(list, 1024, first);
+				else rc = lanesPass<56, 64>(list, 2560, first);
+				first = false;
+				std::vector<uint32_t> again;
+				for (uint32_t i : list) if (widerLanes(outs[i].status)) again.push_back(i);
+				list.swap(again);
+			}
+			if (rc) return rc;
+		}
+		// ---- what is left climbs the wave-per-read ladder: 64 band nodes in LDS; then the general variants, which also carry the
+		// paths for bands with cycles and for ramp redos; last 256 band nodes with large buffers ----
 		st.jobs_retried = 0;
-		int rc = retryPass<64, false>(8192, 3 * 64 + 5 * 2048, 3, 12, true, false);
+		rc = retryPass<64, false>(8192, 3 * 64 + 5 * 2048, 3, 12, true, false);
 		if (rc) return rc;
 		rc = retryPass<64, true>(8192, 3 * 64 + 5 * 4096, 4, 8, false, true);      // only what needs the extra paths: capacity misses go straight on
 		if (rc) return rc;
 		rc = retryPass<256, true>(65536, 3 * 256 + 5 * 8192, 6, 4, true, true);
+		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
 		return rc;
-	}
-
-	static bool isCapacity(int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; }
-	// bands with cycles and ramp redos: only the general variants carry those paths
-	static bool needsGeneral(int s) { return s == GA_UNSUPPORTED_CYCLE || s == GA_UNSUPPORTED_RAMP; }
-
-	template <int MAXN, bool GENERAL> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry, bool takeCapacity, bool takeGeneral)
-	{
-		std::vector<uint32_t> again;
-		for (uint32_t i = 0; i < outs.size(); i++) if ((takeCapacity && isCapacity(outs[i].status)) || (takeGeneral && needsGeneral(outs[i].status))) again.push_back(i);
-		if (again.empty()) return 0;
-		st.jobs_retried += again.size();
-		GaLaunch R = L;
-		uint32_t maxRows = 0;
-		for (uint32_t i : again) maxRows = std::max(maxRows, jobs[i].n_rows);
-		R.cap_cols = capCols;
-		R.trace_cap = maxRows * traceMul + 4096;
-		R.arena_words = 64 + (uint64_t)(maxRows / 64) * (gak::kSliceHdrWords + arenaWordsPerSlice);
-		SlotLayout lay = slotLayout(R.cap_cols, R.max_slices, R.arena_words, R.trace_cap);
-		R.slot_bytes = lay.bytes;
-		size_t freeB = 0, totalB = 0;
-		HIP_OK(hipMemGetInfo(&freeB, &totalB));
-		uint64_t fit = (uint64_t)((freeB + retryScratchBytes) * 0.8) / lay.bytes;
-		uint32_t rslots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * wavesPerCuRetry, fit), again.size()));
-		if ((size_t)rslots * lay.bytes > retryScratchBytes)
-		{
-			if (retryScratch) hipFree(retryScratch);
-			retryScratch = nullptr;
-			retryScratchBytes = 0;
-			HIP_OK(hipMalloc((void**)&retryScratch, (size_t)rslots * lay.bytes));
-			retryScratchBytes = (size_t)rslots * lay.bytes;
-		}
-		if (retryList) hipFree(retryList);
-		retryList = nullptr;
-		HIP_OK(hipMalloc((void**)&retryList, again.size() * 4));
-		HIP_OK(hipMemcpyAsync(retryList, again.data(), again.size() * 4, hipMemcpyHostToDevice, stream));
-		R.scratch = retryScratch;
-		R.job_list = retryList;
-		R.n_jobs = (uint32_t)again.size();
-		HIP_OK(hipMemsetAsync(R.next_job, 0, 16, stream));
-		hipEvent_t a, b;
-		HIP_OK(hipEventCreate(&a));
-		HIP_OK(hipEventCreate(&b));
-		HIP_OK(hipEventRecord(a, stream));
-		hipLaunchKernelGGL((ga_extend_kernel<MAXN, GENERAL>), dim3(rslots), dim3(64), 0, stream, R);
-		HIP_OK(hipGetLastError());
-		HIP_OK(hipEventRecord(b, stream));
-		HIP_OK(hipMemcpyAsync(outs.data(), L.outs, outs.size() * sizeof(GaJobOut), hipMemcpyDeviceToHost, stream));
-		HIP_OK(hipStreamSynchronize(stream));
-		float ms2 = 0;
-		HIP_OK(hipEventElapsedTime(&ms2, a, b));
-		st.kernel_ms += ms2;
-		if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: retry pass <%d,%d>: %zu jobs on %u slots, %.2f ms\n", MAXN, (int)GENERAL, again.size(), rslots, ms2);
-		hipEventDestroy(a);
-		hipEventDestroy(b);
-		return 0;
 	}
 
 	int fetch(std::vector<GaJobOut>& o, std::vector<uint8_t>& traces) override
@@ -299,13 +435,13 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	if (hipSetDevice(device) != hipSuccess) { *status = GA_E_NO_DEVICE; return nullptr; }
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { *status = GA_E_NO_DEVICE; return nullptr; }
-	// node records are addressed with 32-bit lane arithmetic (node << 4 words): up to 2^27 directed nodes
-	if (flat.node_start.size() - 1 >= (1ull << 27)) { *status = GA_E_INVALID; return nullptr; }
+	if (flat.node_start.size() - 1 >= 0xfffffff0ull) { *status = GA_E_INVALID; return nullptr; }      // node indices are 32-bit
 	DevGraph* g = new DevGraph();
 	g->device = device;
 	g->cus = prop.multiProcessorCount;
 	g->g.n_nodes = (uint32_t)(flat.node_start.size() - 1);
-	g->g.reserved = getenv("GA_DIAG_NO_TRACEBACK") ? 1u : 0u;     // diagnostic: counters of the fill phases alone (results are then incomplete)
+	g->g.reserved = 0;
+	g->totalBp = flat.node_start.back();
 	int bad = 0;
 	bad |= g->put(flat.node_start, &g->g.node_start);
 	bad |= g->put(flat.seq2, &g->g.seq2);
@@ -323,13 +459,13 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, const std::vector<uint8_t>& rows, const std::vector<GaJob>& jobs,
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status)
 {
 	DevBatch* b = new DevBatch();
 	b->g = static_cast<DevGraph*>(graph);
 	b->cfg = cfg;
-	int s = b->init(rows, jobs);
+	int s = b->init(rows, eq, jobs);
 	if (s) { delete b; *status = s; return nullptr; }
 	*status = 0;
 	return b;

@@ -160,7 +160,7 @@ static int finalizeGraph(ga_graph* g, int overlap)
 	GaFlatGraph& f = g->flat;
 	f.node_start.assign(g->nodeStart.begin(), g->nodeStart.end());
 	f.node_start.push_back(g->bases.size());
-	f.seq2.assign((g->bases.size() + 15) / 16 + 1, 0);
+	f.seq2.assign((g->bases.size() + 15) / 16 + 8, 0);      // (+ slack: the kernels request base words a little past a node's end)
 	for (size_t i = 0; i < g->bases.size(); i++) f.seq2[i >> 4] |= (uint32_t)(g->bases[i] & 3) << ((i & 15) * 2);
 	f.in_off.assign(n + 1, 0);
 	f.out_off.assign(n + 1, 0);
@@ -621,6 +621,8 @@ int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out)
 	GaRunStats st = b->dev->stats();
 	out->n_jobs = b->jobs.size();
 	out->kernel_ms = st.kernel_ms;
+	out->main_kernel_ms = st.main_ms;
+	out->main_variant = st.main_variant;
 	out->slots = st.slots;
 	out->waves_per_cu = st.waves_per_cu;
 	out->scratch_bytes = st.scratch_bytes;

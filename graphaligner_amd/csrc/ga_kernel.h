@@ -405,10 +405,10 @@ template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN
 		VB live = lane < (cn - base);
 		VI slot = lane + base;
 		VI node = select(live, load_lanes(ws.cn_node + base, cn - base, 0), VI(0));
-		const VI at = node << 4;                                           // GA_NODE_REC_WORDS = 16
-		VI lo = gather(g.node_rec, at);
-		VI hi = gather(g.node_rec, at + 1);
-		VI degs = gather(g.node_rec, at + 3);
+		// (64-bit record addressing: whole-genome graphs have more than 2^27 directed nodes)
+		VI lo = gather_rec(g.node_rec, node, 0);
+		VI hi = gather_rec(g.node_rec, node, 1);
+		VI degs = gather_rec(g.node_rec, node, 3);
 		VI inDeg = degs & 0xffff, outDeg = (degs >> 16) & 0xffff;
 		scatter(ws.cn_startLo, slot, lo, live);
 		scatter(ws.cn_startHi, slot, hi, live);
@@ -419,8 +419,8 @@ template <int MAXN> GA_FN void load_topology(const GaDevGraph& g, WaveState<MAXN
 		{
 			VB hasIn = live && (VI(k) < inDeg);
 			VB hasOut = live && (VI(k) < outDeg);
-			inN[k] = select(hasIn, gather(g.node_rec, at + (8 + k)), VI(-1));
-			outN[k] = select(hasOut, gather(g.node_rec, at + (4 + k)), VI(-1));
+			inN[k] = select(hasIn, gather_rec(g.node_rec, node, 8 + k), VI(-1));
+			outN[k] = select(hasOut, gather_rec(g.node_rec, node, 4 + k), VI(-1));
 			scatter(ws.cn_outNbr, (slot << 2) + k, outN[k], hasOut);
 			inC[k] = VI(-1); inP[k] = VI(-1); outC[k] = VI(-1);
 		}
@@ -1695,7 +1695,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	{
 		if (numSlices < 4) status = GA_ASSERTION;                                // assert(slice.samplingFrequency > 1) (:906)
 	}
-	if (status == GA_OK && kept > 0 && !(g.reserved & 1u))                      // (bit 0 of `reserved`: instruction-count experiments run without the traceback)
+	if (status == GA_OK && kept > 0)
 	{
 		uint8_t* tr = slot.trace;
 		const int big = (int)job.n_rows;                                         // getValueOrMax default = sequence.size()

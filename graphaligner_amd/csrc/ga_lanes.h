@@ -35,6 +35,12 @@ namespace gal {
 #define GAL_FN __device__ __forceinline__
 #endif
 
+#if defined(GA_STAMPS) && !defined(GA_EMULATE)
+GAL_FN uint64_t lap_clock() { return __builtin_readcyclecounter(); }
+#else
+GAL_FN uint64_t lap_clock() { return 0; }
+#endif
+
 constexpr int W = 64;
 constexpr int INF = 0x3fffffff;
 constexpr uint32_t kCutoff = 200000;          // GraphAlignerCommon.h:10
@@ -82,11 +88,11 @@ WaveLayout wave_layout(uint32_t capCols, uint32_t capRows, uint32_t maxSlices, u
 	auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
 	WaveLayout l;
 	uint64_t at = 0;
-	l.endA = at; at = up(at + 256ull * (capCols + 16));
-	l.endB = at; at = up(at + 256ull * (capCols + 16));
+	l.endA = at; at = up(at + 256ull * (capCols + 64));     // (+ slack: operands are requested up to two chunks past a node's end)
+	l.endB = at; at = up(at + 256ull * (capCols + 64));
 	l.hdr = at; at = up(at + 256ull * kHdrWords * (maxSlices + 1));
-	l.snodes = at; at = up(at + 256ull * 2 * N * (maxSlices + 1));
-	l.moves = at; at = up(at + 256ull * ((capMoves + 3) / 4 + 1));
+	l.snodes = at; at = up(at + 256ull * 2 * N * (maxSlices + 2));
+	l.moves = at; at = up(at + 256ull * ((capMoves + 3) / 4 + 16));
 	l.arena = at; at = up(at + (uint64_t)kRecBytes * 64 * (capRows + 16));
 	l.bytes = at;
 	return l;
@@ -114,6 +120,8 @@ template <int N> struct Lay
 	static constexpr int OB_POST = 0, OB_COLOR = N, OB_STSLOT = 2 * N, OB_STCUR = 3 * N;
 	// during the traceback: node lists of the slice traced through and of the slice above it
 	static constexpr int T_CN = 0, T_CB = N, T_PN = 2 * N, T_PB = 3 * N;
+	static constexpr int T_WIN = 4 * N, T_WINCOLS = (6 * N) / 5 < 16 ? (6 * N) / 5 : 16;       // window of column records (5 words each)
+	static_assert(4 * N + T_WINCOLS * 5 <= 10 * N && T_WINCOLS >= 8, "traceback window does not fit");
 	static constexpr int WORDS = 10 * N;
 	static_assert((2 * N + HB + 3) / 4 <= N, "hash bytes do not fit");
 };
@@ -140,6 +148,7 @@ struct LaneMem
 	uint32_t* snodes;
 	uint32_t* moves;
 	uint8_t* arena;
+	uint64_t* stage;              // device: the wave's LDS image of the open block of 8 arena rows
 	int lane;
 };
 
@@ -163,6 +172,7 @@ struct LaneState
 	uint64_t nColumns;
 	uint32_t rampUntil;
 	bool useRamp;
+	uint64_t laps[4];             // diagnostic builds: cycles inside the traceback (fast steps, general steps, hand-over)
 };
 
 // ---- graph access ---------------------------------------------------------------------------------------------
@@ -338,19 +348,27 @@ template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, La
 	typedef Lay<N> LY;
 	const Lds& l = m.lds;
 	const int cn = st.cn;
+	const int pn = st.pn;
 	for (int s = 0; s < cn; s++)
 	{
 		const uint32_t* rec = g_rec(g, l.rd(LY::C_NODE + s));
 		const uint32_t outDeg = rec[3] >> 16, inDeg = rec[3] & 0xffffu;
 		if (outDeg > 4 || inDeg > 4) return GA_PUNT;
-		uint32_t slots = 0;
+		uint32_t slots = 0, inCur = 0, inPrv = 0;
 		for (uint32_t e = 0; e < 4; e++)
 		{
-			int x = -1;
+			int x = -1, ic = -1, ip = -1;
 			if (e < outDeg) x = find_in(l, LY::C_NODE, cn, rec[4 + e]);
+			if (e < inDeg) { ic = find_in(l, LY::C_NODE, cn, rec[8 + e]); ip = find_in(l, LY::P_NODE, pn, rec[8 + e]); }
 			slots |= (x < 0 ? kNone : (uint32_t)x) << (8 * e);
+			inCur |= (ic < 0 ? kNone : (uint32_t)ic) << (8 * e);
+			inPrv |= (ip < 0 ? kNone : (uint32_t)ip) << (8 * e);
 		}
 		l.wr(LY::C_OUT + s, slots);
+		// where the node's in-neighbours sit in the current / the previous band: read once when the fill starts the node
+		// (P_PACK is free by now; C_MIN[s] is only written when node s is finished)
+		l.wr(LY::P_PACK + s, inCur);
+		l.wr(LY::C_MIN + s, inPrv);
 		l.wrb(LY::X_ORD, LY::OB_COLOR + s, 0);
 	}
 	int emitted = 0;
@@ -453,168 +471,310 @@ GAL_FN int col_value(uint64_t vp, uint64_t vn, int before, int row)            /
 	return before + __builtin_popcountll(vp & mask) - __builtin_popcountll(vn & mask);
 }
 
+// (records are 8-byte aligned: three 64-bit words)
 template <int R> GAL_FN void rec_store(const LaneMem& m, uint32_t row, const Col& c, uint32_t endWord)
 {
-	uint32_t* p = (uint32_t*)(m.arena + rec_off<R>(row, m.lane));
-	p[0] = (uint32_t)c.vp; p[1] = (uint32_t)(c.vp >> 32); p[2] = (uint32_t)c.vn; p[3] = (uint32_t)(c.vn >> 32);
-	p[4] = (uint32_t)c.before; p[5] = endWord;
+	uint64_t* p = (uint64_t*)(m.arena + rec_off<R>(row, m.lane));
+	p[0] = c.vp; p[1] = c.vn; p[2] = (uint64_t)(uint32_t)c.before | ((uint64_t)endWord << 32);
 }
 template <int R> GAL_FN void rec_load(const LaneMem& m, uint32_t row, Col& c, uint32_t& endWord)
 {
-	const uint32_t* p = (const uint32_t*)(m.arena + rec_off<R>(row, m.lane));
-	c.vp = ((uint64_t)p[1] << 32) | p[0];
-	c.vn = ((uint64_t)p[3] << 32) | p[2];
-	c.before = (int)p[4];
-	endWord = p[5];
+	const uint64_t* p = (const uint64_t*)(m.arena + rec_off<R>(row, m.lane));
+	c.vp = p[0];
+	c.vn = p[1];
+	const uint64_t t = p[2];
+	c.before = (int)(uint32_t)t;
+	endWord = (uint32_t)(t >> 32);
 }
 
-GAL_FN uint64_t eq_for(const LaneState& st, int base)
+
+#ifndef GA_EMULATE
+// the wave's 8 x 64 records of arena block `block` leave as twelve coalesced 1 KB stores: 16-byte chunk q of the 12 KB block
+// belongs to lane q / 12 (rec_off<8>: lane-major inside a block)
+GAL_FN void stage_flush(const LaneMem& m, uint32_t block)
 {
-	return (base & 2) ? ((base & 1) ? st.e3 : st.e2) : ((base & 1) ? st.e1 : st.e0);
+	__builtin_amdgcn_wave_barrier();
+	uint8_t* dst = m.arena + (uint64_t)block * (64 * 8 * kRecBytes);
+#pragma unroll
+	for (int j = 0; j < 12; j++)
+	{
+		const uint32_t q = (uint32_t)m.lane + 64u * (uint32_t)j;
+		const uint32_t ln = q / 12u, part = q % 12u;
+		const uint64_t* sp = m.stage + ln * 25 + part * 2;
+		const uint64_t a = sp[0], b = sp[1];
+		uint64_t* d = (uint64_t*)(dst + (uint64_t)q * 16);
+		d[0] = a; d[1] = b;
+	}
+	__builtin_amdgcn_wave_barrier();
+}
+#endif
+
+GAL_FN uint64_t eq_for(uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, int base)
+{
+	const uint64_t lo = (base & 1) ? e1 : e0, hi = (base & 1) ? e3 : e2;
+	return (base & 2) ? hi : lo;
 }
 GAL_FN int g_base(const GaDevGraph& g, uint64_t col) { return (int)((g.seq2[col >> 4] >> ((col & 15) * 2)) & 3); }
 
 // ---- fill one slice: every band node in processing order (calculateSlice / calculateNode, GraphAligner.h:2331-2451,
 // 1457-1573), one column per step.  The bookkeeping of the virtual row j-1 (forceComponentZeroRow's chain :1939-1944,
 // scoreBeforeStart / scoreBeforeExists of getNextSlice :1358-1370, the re-entry test :1541-1546) runs along the node
-// with the columns.
-template <int N, int R>
-GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uint32_t slice, bool active)
+// with the columns.  A lone wave is bound by instruction issue and by exposed latency, so: the columns of a node go in
+// chunks of U whose operands (previous end words, graph bases) are requested one chunk ahead; the next node's graph record
+// and first previous end word are requested while this node is computed; and a node entered from the node just finished
+// takes that node's last column from registers.
+// Inside a node the vertical re-entry needs no merge: the cell above is at most one below the left column's row j-1
+// (adjacent cells of the previous slice's last row), so the step simply starts from min(calc, above).
+//
+// Where the records go.  The lanes of a wave take their k-th node together and step its columns together, so step t of the
+// wave produces (up to) one record per lane; those 64 records are row t of the wave's arena.  Stored lane by lane they
+// would be 64 partial cache-line writes per store instruction, and the L2's request rate, not bytes, is what such a kernel
+// runs into.  Instead a lane drops its record into an LDS image of the current block of 8 rows, and when the block is complete
+// the whole wave writes its 12 KB as twelve fully coalesced 1 KB stores.  In memory a lane's 8 columns of a block are
+// contiguous (192 B), which is what the traceback wants: it reads 16 columns of one lane at a time.
+// (The host emulation stores directly; rows there are simply per lane.)
+constexpr int kStageWords64 = 25;            // LDS image: lane stride 200 B (conflict-free 8-byte writes), 8 slots of 3 words
+#ifndef GA_EMULATE
+GAL_FN uint32_t wave_max(uint32_t v)
+{
+	for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = v > o ? v : o; }
+	return v;
+}
+#else
+GAL_FN uint32_t wave_max(uint32_t v) { return v; }
+#endif
+
+template <int N, int U>
+GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uint32_t slice, bool active, uint32_t& rowTop, uint32_t capRows, uint32_t capCols)
 {
 	typedef Lay<N> LY;
 	const Lds& l = m.lds;
 	const bool j0 = slice == 0;
-	const int pn = st.pn, cn = st.cn;
-	int ord = active ? cn - 1 : -1;
+	// (register copies: the match words must not be picked by an indexed load from the lane state)
+	const uint64_t e0 = st.e0, e1 = st.e1, e2 = st.e2, e3 = st.e3;
+	const int rawAbove = st.rawAbove;
+	const int nRowsP1 = (int)st.nRows + 1;
+	int ord = active ? st.cn - 1 : -1;
 	int sliceMin = INF, minSlot = -1;
 	uint32_t minOffset = 0;
 	int status = GA_OK;
+	uint32_t tick = rowTop;                       // arena row of the wave's next step
+	// requested ahead for the node at `ord`
+	uint32_t nFirstLo = 0, nFirstHi = 0, nPend0 = 0;
+	auto request = [&](int o) {
+		// (unconditional: a lane without a next node asks for node 0's record and a dummy end word)
+		const int s2 = o >= 0 ? (int)l.rdb(LY::X_ORD, LY::OB_POST + o) : 0;
+		const uint32_t* rec2 = g_rec(g, o >= 0 ? l.rd(LY::C_NODE + s2) : 0u);
+		nFirstLo = rec2[0]; nFirstHi = rec2[1];
+		const uint32_t pinfo2 = o >= 0 ? l.rd(LY::C_PINFO + s2) : (kNone << 16);
+		nPend0 = m.endPrev[(uint64_t)((pinfo2 >> 16) != kNone ? (pinfo2 & 0xffffu) : 0u) * 64];
+	};
+	request(ord);
+	// the node finished last: its last column stays in c / exists
+	Col c; c.vp = 0; c.vn = 0; c.before = 0;
+	bool exists = false;
+	int doneSlot = -1;
+	// a record leaves: into the block image (device: slot = the step's place in its chunk) or straight to the arena (emulation)
+	auto put = [&](bool on, uint32_t row, int slot, const Col& col, uint32_t endWord) {
+#ifdef GA_EMULATE
+		(void)slot;
+		if (on) rec_store<8>(m, row, col, endWord);
+#else
+		(void)row;
+		if (on)
+		{
+			uint64_t* sp = m.stage + m.lane * kStageWords64 + slot * 3;
+			sp[0] = col.vp; sp[1] = col.vn; sp[2] = (uint64_t)(uint32_t)col.before | ((uint64_t)endWord << 32);
+		}
+#endif
+	};
+	// a finished column of THIS slice read back (a node entered from a node that is not the one just finished)
+	auto readBack = [&](uint32_t row, Col& col, uint32_t& endWord) {
+#ifndef GA_EMULATE
+		__threadfence_block();                     // the block was written by other lanes of this wave
+#endif
+		rec_load<8>(m, row, col, endWord);
+	};
 #ifdef GA_EMULATE
 	while (ord >= 0)
 #else
 	while (__ballot(ord >= 0))
 #endif
 	{
-		if (ord < 0) continue;
-		const int s = (int)l.rdb(LY::X_ORD, LY::OB_POST + ord);
-		const uint32_t node = l.rd(LY::C_NODE + s);
-		const uint32_t geo = l.rd(LY::C_GEO + s), pinfo = l.rd(LY::C_PINFO + s);
+		const bool act = ord >= 0;
+		const int s = act ? (int)l.rdb(LY::X_ORD, LY::OB_POST + ord) : 0;
+		const uint32_t geo = act ? l.rd(LY::C_GEO + s) : 0u, pinfo = act ? l.rd(LY::C_PINFO + s) : (kNone << 16);
+		const uint32_t inCur = act ? l.rd(LY::P_PACK + s) : 0xffffffffu, inPrv = act ? l.rd(LY::C_MIN + s) : 0xffffffffu;
 		const uint32_t colBase = geo & 0xffffu, len = geo >> 16;
 		const bool inPrev = (pinfo >> 16) != kNone;
 		const uint32_t pbase = pinfo & 0xffffu;
-		const uint32_t* rec = g_rec(g, node);
-		const uint64_t firstCol = ((uint64_t)rec[1] << 32) | rec[0];
-		const uint32_t inDeg = rec[3] & 0xffffu;
+		const uint64_t firstCol = ((uint64_t)nFirstHi << 32) | nFirstLo;
+		const uint32_t pend0raw = nPend0;
+		request(ord - 1);
 		const bool aboveAlways = j0 && inPrev;                                   // "previousEq" (:1503): raw char ==, not characterMatch
 		const uint32_t* pend = m.endPrev + (uint64_t)pbase * 64;
-		// ---- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ----
-		const uint32_t pend0raw = inPrev ? pend[0] : 0u;
-		const int pend0 = inPrev ? ew_end(pend0raw) : INF;
-		int zero0 = pend0;
-		bool hasIn = false;
-		int cs[4], pm[4];
-		Col left[4];
-		uint32_t leftEw[4];
-		for (uint32_t e = 0; e < 4; e++)
-		{
-			cs[e] = -1; pm[e] = -1; leftEw[e] = 0; left[e].vp = 0; left[e].vn = 0; left[e].before = 0;
-			if (e >= inDeg) continue;
-			const uint32_t nb = rec[8 + e];
-			cs[e] = find_in(l, LY::C_NODE, cn, nb);
-			pm[e] = find_in(l, LY::P_NODE, pn, nb);
-			if (cs[e] < 0 && pm[e] < 0) continue;
-			hasIn = true;
-			if (cs[e] >= 0)
-			{
-				const uint32_t ng = l.rd(LY::C_GEO + cs[e]);
-				rec_load<R>(m, st.rowBase + (ng & 0xffffu) + (ng >> 16) - 1, left[e], leftEw[e]);
-				zero0 = zero0 < left[e].before + 1 ? zero0 : left[e].before + 1;
-			}
-			if (pm[e] >= 0)
-			{
-				const int pe = ew_end(l.rd(LY::P_END + pm[e]));
-				zero0 = zero0 < pe + 1 ? zero0 : pe + 1;
-			}
-		}
-		const int base0 = g_base(g, firstCol);
-		const uint64_t eq0 = eq_for(st, base0);
-		const bool aboveEq0 = aboveAlways || (!j0 && st.rawAbove == base0);
-		const bool exists0 = inPrev && pend0 == zero0;                           // scoreBeforeExists from :1989 (scoreEndExists is always true on this path)
-		Col c;
-		bool exists;
-		if (!hasIn)
-		{
-			// source node (:1475-1499): a vertical run from the cell above
-			if (j0 && inPrev) { c.vp = ~1ull | (uint64_t)(((eq0 & 1) != 0) ? 0 : 1); c.vn = 0; c.before = pend0; exists = true; }
-			else if (inPrev) { c.vp = ~0ull; c.vn = 0; c.before = pend0; exists = true; }
-			else { c.vp = ~1ull; c.vn = 0; c.before = (int)st.nRows + 1; exists = false; }
-		}
-		else
-		{
-			// node start: cell-wise minimum over the in-neighbours' last columns advanced one step (getNodeStartSlice :1270-1315)
-			bool first = true;
-			c.vp = 0; c.vn = 0; c.before = 0;
-			for (uint32_t e = 0; e < 4; e++)
-			{
-				if (cs[e] < 0 && pm[e] < 0) continue;
-				Col x;
-				uint64_t eq = eq0;
-				bool leftExists;
-				if (cs[e] >= 0) { x = left[e]; leftExists = ((leftEw[e] >> 2) & 1) != 0; }
-				else
-				{
-					// neighbour only in the previous band: vertical source column, only row j may match (:1294-1301)
-					x.vp = ~0ull; x.vn = 0; x.before = ew_end(l.rd(LY::P_END + pm[e]));
-					leftExists = true;
-					eq &= 1ull;
-				}
-				int calc = x.before + 1;
-				if (exists0 && pm[e] >= 0)
-				{
-					const int viaDiag = ew_end2(l.rd(LY::P_END + pm[e])) + (aboveEq0 ? 0 : 1);
-					calc = calc < viaDiag ? calc : viaDiag;
-				}
-				column_step(x, eq, !(leftExists && pm[e] >= 0), calc);
-				if (first) { c = x; first = false; } else column_merge(c, x);
-			}
-			exists = exists0;
-			if (inPrev && c.before > pend0) { column_reenter(c, c.before - pend0); exists = true; }     // vertical re-entry (:1504-1509)
-		}
-		// ---- the node's columns ----
-		int nodeMin = INF;
-		int zero = zero0;
-		int above2 = ew_end2(pend0raw);
+		static_assert(U == 8, "a chunk is one block of 8 arena rows");
+		const uint32_t nChunks = (wave_max(len) + U - 1) / U;                    // the wave's nodes go in chunks of U columns = blocks of U arena rows
+		if (tick + nChunks * U + U > capRows) { if (act) status = GA_CAP_ARENA; ord = -1; break; }
+		const uint32_t t0 = tick;                                                // arena row of the node's column 0 (a multiple of U)
+		// operands of the first chunk (columns 0 .. U-1; column 0 itself comes from the node start below).  Requests are unconditional
+		// (lanes without a previous column read a valid dummy row) so that the compiler can count them.
+		const uint32_t* pendSafe = (act && inPrev) ? pend : m.endPrev;
+		const uint32_t* seqSafe = g.seq2 + (act ? (firstCol >> 4) : 0);
+		const uint32_t sh0 = act ? (uint32_t)(firstCol & 15) * 2 : 0u;           // chunks are 8 columns: the base word's phase alternates with firstCol's
+		uint32_t pe[U];
+		uint64_t bw;
+#pragma unroll
+		for (int i = 0; i < U; i++) pe[i] = pendSafe[(uint64_t)i * 64];
+		bw = (uint64_t)seqSafe[0] | ((uint64_t)seqSafe[1] << 32);
+		int nodeMin = INF, zero = 0, above2 = 0;
 		uint32_t endWord = 0;
-		for (uint32_t w = 0; w < len; w++)
-		{
-			if (w > 0)
+		const uint32_t dummyCol = capCols + 32;                                  // where lanes without a column this step send their end word
+		auto emit = [&](bool on, uint32_t w, int slot) {
+			if (on)
 			{
-				const int base = g_base(g, firstCol + w);
-				const uint32_t peRaw = inPrev ? pend[(uint64_t)w * 64] : 0u;
-				const int pe = inPrev ? ew_end(peRaw) : INF;
-				const int z1 = zero + 1;
-				zero = z1 < pe ? z1 : pe;                                          // :1939-1944
-				const bool existsW = inPrev && pe == zero;
-				const bool aboveEq = aboveAlways || (!j0 && st.rawAbove == base);
-				int calc = c.before + 1;
-				if (existsW) { const int viaDiag = above2 + 1 - (aboveEq ? 1 : 0); calc = calc < viaDiag ? calc : viaDiag; }    // :1361-1370
-				column_step(c, eq_for(st, base), !exists, calc);
-				exists = existsW;
-				if (inPrev && calc > pe) { column_reenter(c, calc - pe); exists = true; }             // :1541-1546
-				above2 = ew_end2(peRaw);
+				const int end = col_end(c);
+				endWord = ((uint32_t)end << 3) | (exists ? 4u : 0u) | ((uint32_t)(c.vn >> 63) << 1) | (uint32_t)(c.vp >> 63);
+				nodeMin = end < nodeMin ? end : nodeMin;
+				if (end <= sliceMin) { sliceMin = end; minSlot = s; minOffset = w; }  // the LAST column attaining the minimum (:1551-1559, 2410-2418)
 			}
-			const int end = col_end(c);
-			endWord = ((uint32_t)end << 3) | (exists ? 4u : 0u) | ((uint32_t)(c.vn >> 63) << 1) | (uint32_t)(c.vp >> 63);
-			rec_store<R>(m, st.rowBase + colBase + w, c, endWord);
-			m.endCur[(uint64_t)(colBase + w) * 64] = endWord;
-			nodeMin = end < nodeMin ? end : nodeMin;
-			if (end <= sliceMin) { sliceMin = end; minSlot = s; minOffset = w; }  // the LAST column attaining the minimum (:1551-1559, 2410-2418)
+			m.endCur[(uint64_t)(on ? colBase + w : dummyCol) * 64] = endWord;
+			put(on, t0 + w, slot, c, endWord);
+		};
+		if (act)
+		{
+			// ---- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ----
+			const int pend0 = inPrev ? ew_end(pend0raw) : INF;
+			int zero0 = pend0;
+			bool hasIn = false;
+			Col left[4];
+			bool leftEx[4];
+#pragma unroll
+			for (int e = 0; e < 4; e++)
+			{
+				const uint32_t ic = (inCur >> (8 * e)) & 0xffu, ip = (inPrv >> (8 * e)) & 0xffu;
+				left[e].vp = 0; left[e].vn = 0; left[e].before = 0; leftEx[e] = false;
+				if (ic == kNone && ip == kNone) continue;
+				hasIn = true;
+				if (ic != kNone)
+				{
+					if ((int)ic == doneSlot) { left[e] = c; leftEx[e] = exists; }
+					else
+					{
+						// (C_PINFO of a started node holds the arena row of its column 0)
+						uint32_t ew;
+						readBack(l.rd(LY::C_PINFO + (int)ic) + (l.rd(LY::C_GEO + (int)ic) >> 16) - 1, left[e], ew);
+						leftEx[e] = ((ew >> 2) & 1) != 0;
+					}
+					zero0 = zero0 < left[e].before + 1 ? zero0 : left[e].before + 1;
+				}
+				if (ip != kNone)
+				{
+					const int pe1 = ew_end(l.rd(LY::P_END + (int)ip)) + 1;
+					zero0 = zero0 < pe1 ? zero0 : pe1;
+				}
+			}
+			const int base0 = (int)(bw >> sh0) & 3;
+			const uint64_t eq0 = eq_for(e0, e1, e2, e3, base0);
+			const bool aboveEq0 = aboveAlways || (!j0 && rawAbove == base0);
+			const bool exists0 = inPrev && pend0 == zero0;                       // scoreBeforeExists from :1989 (scoreEndExists is always true on this path)
+			if (!hasIn)
+			{
+				// source node (:1475-1499): a vertical run from the cell above
+				if (j0 && inPrev) { c.vp = ~1ull | (uint64_t)(((eq0 & 1) != 0) ? 0 : 1); c.vn = 0; c.before = pend0; exists = true; }
+				else if (inPrev) { c.vp = ~0ull; c.vn = 0; c.before = pend0; exists = true; }
+				else { c.vp = ~1ull; c.vn = 0; c.before = nRowsP1; exists = false; }
+			}
+			else
+			{
+				// node start: cell-wise minimum over the in-neighbours' last columns advanced one step (getNodeStartSlice :1270-1315)
+				bool first = true;
+#pragma unroll
+				for (int e = 0; e < 4; e++)
+				{
+					const uint32_t ic = (inCur >> (8 * e)) & 0xffu, ip = (inPrv >> (8 * e)) & 0xffu;
+					if (ic == kNone && ip == kNone) continue;
+					Col x = left[e];
+					uint64_t eq = eq0;
+					bool leftExists = leftEx[e];
+					if (ic == kNone)
+					{
+						// neighbour only in the previous band: vertical source column, only row j may match (:1294-1301)
+						x.vp = ~0ull; x.vn = 0; x.before = ew_end(l.rd(LY::P_END + (int)ip));
+						leftExists = true;
+						eq &= 1ull;
+					}
+					int calc = x.before + 1;
+					if (exists0 && ip != kNone)
+					{
+						const int viaDiag = ew_end2(l.rd(LY::P_END + (int)ip)) + (aboveEq0 ? 0 : 1);
+						calc = calc < viaDiag ? calc : viaDiag;
+					}
+					column_step(x, eq, !(leftExists && ip != kNone), calc);
+					if (first) { c = x; first = false; } else column_merge(c, x);
+				}
+				exists = exists0;
+				if (inPrev && c.before > pend0) { column_reenter(c, c.before - pend0); exists = true; }     // vertical re-entry (:1504-1509)
+			}
+			zero = zero0;
+			above2 = ew_end2(pend0raw);
+			l.wr(LY::C_PINFO + s, t0);                                           // from now on: where the node's records are
 		}
-		if (c.before != zero) { status = GA_ASSERTION; ord = -1; continue; }      // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
-		l.wr(LY::C_MIN + s, (uint32_t)nodeMin);
-		l.wr(LY::C_END + s, endWord);
-		ord--;
+		// ---- the node's columns, U per chunk ----
+		for (uint32_t j = 0; j < nChunks; j++)
+		{
+			const uint32_t w0 = j * U;
+			const uint32_t sh = (sh0 + 2 * w0) & 31u;                            // bit position of column w0's base inside bw
+			// operands of the next chunk
+			uint32_t pe2[U];
+			uint64_t bw2;
+#pragma unroll
+			for (int i = 0; i < U; i++) pe2[i] = pendSafe[(uint64_t)(w0 + U + (uint32_t)i) * 64];
+			{ const uint32_t* q = seqSafe + (((sh0 >> 1) + w0 + U) >> 4); bw2 = (uint64_t)q[0] | ((uint64_t)q[1] << 32); }
+#pragma unroll
+			for (int i = 0; i < U; i++)
+			{
+				const uint32_t w = w0 + (uint32_t)i;
+				const bool on = act && w < len;
+				if (on && w > 0)
+				{
+					const int base = (int)(bw >> (sh + 2 * i)) & 3;
+					const uint32_t peRaw = pe[i];
+					const int pv = inPrev ? ew_end(peRaw) : INF;
+					const int z1 = zero + 1;
+					zero = z1 < pv ? z1 : pv;                                      // :1939-1944
+					const bool existsW = inPrev && pv == zero;
+					const bool aboveEq = aboveAlways || (!j0 && rawAbove == base);
+					int calc = c.before + 1;
+					if (existsW) { const int viaDiag = above2 + 1 - (aboveEq ? 1 : 0); calc = calc < viaDiag ? calc : viaDiag; }    // :1361-1370
+					const bool reenter = calc > pv;                                // :1541-1546 (pv = INF when the node is new to the band)
+					column_step(c, eq_for(e0, e1, e2, e3, base), !exists, reenter ? pv : calc);
+					exists = reenter || existsW;
+					above2 = ew_end2(peRaw);
+				}
+				emit(on, w, i);
+			}
+#ifndef GA_EMULATE
+			stage_flush(m, (t0 >> 3) + j);                                       // the chunk's block of U rows is complete
+#endif
+#pragma unroll
+			for (int i = 0; i < U; i++) pe[i] = pe2[i];
+			bw = bw2;
+		}
+		tick = t0 + nChunks * U;
+		if (act)
+		{
+			if (c.before != zero) { status = GA_ASSERTION; ord = -1; }            // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
+			else
+			{
+				l.wr(LY::C_MIN + s, (uint32_t)nodeMin);
+				l.wr(LY::C_END + s, endWord);
+				doneSlot = s;
+				ord--;
+			}
+		}
 	}
+	rowTop = tick;
 	if (active)
 	{
 		st.sliceMin = sliceMin; st.minSlot = minSlot; st.minOffset = minOffset;
@@ -635,6 +795,7 @@ template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m
 	st.nPushed = 0; st.nRun = 0; st.maxBandNodes = 0; st.kept = 0; st.nColumns = 0; st.rampUntil = 0; st.useRamp = false;
 	st.nRows = 0; st.numSlices = 0; st.seedNode = 0; st.eq = L.eq;
 	st.logCorrect = 0; st.logWrong = 0;
+	st.laps[0] = st.laps[1] = st.laps[2] = st.laps[3] = 0;
 	if (!hasJob) return;
 	const GaJob job = L.jobs[jobIndex];
 	st.nRows = job.n_rows;
@@ -705,13 +866,13 @@ template <int N> GAL_FN void lane_end_slice(const GaLanesLaunch& L, LaneMem& m, 
 	uint32_t* h = m.hdr + (uint64_t)slice * kHdrWords * 64;
 	h[0] = (uint32_t)cn; h[64] = st.totalCols; h[128] = (uint32_t)st.sliceMin; h[192] = (uint32_t)st.minSlot; h[256] = st.minOffset;
 	h[320] = (uint32_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0));
-	h[384] = st.rowBase;
+	h[384] = 0;                                                                   // (node rows below are absolute)
 	uint32_t* sn = m.snodes + (uint64_t)slice * 2 * N * 64;
 	for (int k = 0; k < cn; k++)
 	{
 		const uint32_t node = l.rd(LY::C_NODE + k), geo = l.rd(LY::C_GEO + k);
 		sn[(uint64_t)(2 * k) * 64] = node;
-		sn[(uint64_t)(2 * k + 1) * 64] = geo & 0xffffu;
+		sn[(uint64_t)(2 * k + 1) * 64] = l.rd(LY::C_PINFO + k);                       // arena row of the node's column 0
 		// ... and the slice becomes the state the next one is computed from
 		l.wr(LY::P_NODE + k, node);
 		l.wr(LY::P_END + k, l.rd(LY::C_END + k));
@@ -727,7 +888,7 @@ template <int N> GAL_FN void lane_end_slice(const GaLanesLaunch& L, LaneMem& m, 
 }
 
 // ---- traceback (getTraceFromTable :894-957 with pickBacktracePredecessor :493-591) and the job's output ----------
-template <int N, int R> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& m, LaneState& st, bool hasJob)
+template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& m, LaneState& st, bool hasJob)
 {
 	typedef Lay<N> LY;
 	if (!hasJob) return;
@@ -757,16 +918,29 @@ template <int N, int R> GAL_FN void lane_finish(const GaLanesLaunch& L, const La
 		const int big = (int)st.nRows;                                            // getValueOrMax default = sequence.size()
 		uint32_t sIdx = kept - 1;
 		uint32_t nN = 0, pN = 0, curRow = 0, prvRow = 0;
+		uint32_t aN = 0, aRow = 0;                                                // header of the slice two above, requested one slice change ahead
 		int tCN = LY::T_CN, tCB = LY::T_CB, tPN = LY::T_PN, tPB = LY::T_PB;
-		auto loadTable = [&](int tn, int tb, uint32_t sl, uint32_t& count, uint32_t& rowBase) {
+		auto loadHeader = [&](uint32_t sl, uint32_t& count, uint32_t& rowBase) {
 			const uint32_t* h = m.hdr + (uint64_t)sl * kHdrWords * 64;
 			count = h[0];
 			rowBase = h[384];
-			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * 64;
-			for (uint32_t k = 0; k < count; k++) { l.wr(tn + (int)k, sn[(uint64_t)(2 * k) * 64]); l.wr(tb + (int)k, sn[(uint64_t)(2 * k + 1) * 64]); }
 		};
-		loadTable(tCN, tCB, sIdx, nN, curRow);
-		if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN, prvRow);
+		auto loadTable = [&](int tn, int tb, uint32_t sl, uint32_t count) {
+			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * 64;
+			for (uint32_t k = 0; k < count; k += 4)
+			{
+				uint32_t a[8];
+#pragma unroll
+				for (int i = 0; i < 8; i++) a[i] = sn[(uint64_t)(2 * k + (uint32_t)i) * 64];      // (rows past `count` are inside the plane)
+#pragma unroll
+				for (int i = 0; i < 4; i++) if (k + (uint32_t)i < count) { l.wr(tn + (int)k + i, a[2 * i]); l.wr(tb + (int)k + i, a[2 * i + 1]); }
+			}
+		};
+		loadHeader(sIdx, nN, curRow);
+		if (sIdx > 0) loadHeader(sIdx - 1, pN, prvRow);
+		if (sIdx > 1) loadHeader(sIdx - 2, aN, aRow);
+		loadTable(tCN, tCB, sIdx, nN);
+		if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN);
 		const uint32_t* h = m.hdr + (uint64_t)sIdx * kHdrWords * 64;
 		out.score = (int32_t)h[128];
 		uint32_t node = l.rd(tCN + (int)h[192]);
@@ -776,106 +950,248 @@ template <int N, int R> GAL_FN void lane_finish(const GaLanesLaunch& L, const La
 		uint64_t e[4];
 		auto loadEq = [&](uint32_t sl) { const uint64_t* q = st.eq + (uint64_t)sl * 5; e[0] = q[0]; e[1] = q[1]; e[2] = q[2]; e[3] = q[3]; };
 		loadEq(sIdx);
-		// cell value from the stored words (getValueOrMax, GraphAligner.h:2008-2017)
-		auto valueIn = [&](int tn, int tb, uint32_t count, uint32_t rowBase, uint32_t n, uint32_t off, int r) -> int {
+		// the record of column (n, off) in the slice whose tables are (tn, tb); false when the node is not in that slice
+		auto recordIn = [&](int tn, int tb, uint32_t count, uint32_t rowBase, uint32_t n, uint32_t off, Col& c) -> bool {
 			const int sl = find_in(l, tn, (int)count, n);
-			if (sl < 0) return big;
-			Col c; uint32_t ew;
-			rec_load<R>(m, rowBase + l.rd(tb + sl) + off, c, ew);
-			return col_value(c.vp, c.vn, c.before, r);
+			c.vp = 0; c.vn = 0; c.before = 0;
+			if (sl < 0) return false;
+			uint32_t ew;
+			rec_load<8>(m, rowBase + l.rd(tb + sl) + off, c, ew);
+			return true;
 		};
 		uint32_t pack = 0;
-		while (true)
-		{
-			if (row == 0xffffffffu) break;                                          // reached the row before the first one
-			if (len + 4 >= L.cap_moves) { status = GA_CAP_TRACE; break; }
-			const int r = (int)(row - sIdx * W);
-			const int slot = find_in(l, tCN, (int)nN, node);
-			if (slot < 0) { status = GA_ASSERTION; break; }                        // assert(slice.scores.hasNode(nodeIndex)) (:498)
-			const uint32_t colRow = curRow + l.rd(tCB + slot) + offset;
-			Col c; uint32_t ew;
-			rec_load<R>(m, colRow, c, ew);
-			const int here = col_value(c.vp, c.vn, c.before, r);
-			if (row == 0 && node == st.seedNode && (here == 0 || here == 1)) { row = 0xffffffffu; continue; }     // free start (:500)
-			const uint32_t* rec = g_rec(g, node);
-			const uint64_t firstCol = ((uint64_t)rec[1] << 32) | rec[0];
-			const int base = g_base(g, firstCol + offset);
-			const bool match = ((e[base] >> r) & 1) != 0;
-			int res = 0, via = 0;
-			const uint32_t curNode = node, curOffset = offset;
-			auto decide = [&](int horizontal, int diagonal, uint32_t un, uint32_t uo) -> int {
-				if (horizontal < here - 1) return -1;
-				if (horizontal == here - 1) { node = un; offset = uo; return 1; }
-				if (match)
+		// Most steps stay inside a node and inside a slice.  Those run in a tight loop on two records held in registers (the current
+		// column and the one to its left) that are fed from a window of kWin consecutive columns of the node kept in LDS.  Everything
+		// rare -- filling the window, leaving a node through its first column, a step at the slice's first row, a change of
+		// slice -- is the general step below.  Rare per lane is not rare per wave: with 64 lanes some lane needs the general step
+		// in almost every iteration, so a lane that needs it WAITS while the others take fast steps, and the wave runs the general step
+		// for all waiting lanes at once when no lane can take a fast step any more; every general step also tops the window up, so the
+		// lanes leave it with about the same number of fast steps ahead of them.  (The order in which lanes step does not change
+		// what any of them computes; the host emulation simply runs each lane on its own.)
+		constexpr int kWin = Lay<N>::T_WINCOLS;
+		constexpr int tWIN = Lay<N>::T_WIN;
+		Col q0, q1;
+		q0.vp = q0.vn = 0; q0.before = 0; q1 = q0;
+		bool needSetup = true;
+		uint32_t slotRow = 0, recNode = 0xffffffffu, inDeg = 0;
+		uint32_t nb[4] = {0, 0, 0, 0}, nbLen[4] = {0, 0, 0, 0};
+		uint64_t firstCol = 0, bw = 0, bwCol0 = ~0ull;
+		uint32_t wLo = 1, wHi = 0;                    // columns of `node` (in slice sIdx) the window holds: [wLo, wHi], empty when wLo > wHi
+		bool tracing = true;
+		auto winRead = [&](uint32_t o, Col& c) {
+			const int at = tWIN + (int)(o - wLo) * 5;
+			c.vp = ((uint64_t)l.rd(at + 1) << 32) | l.rd(at);
+			c.vn = ((uint64_t)l.rd(at + 3) << 32) | l.rd(at + 2);
+			c.before = (int)l.rd(at + 4);
+		};
+		auto putMove = [&](int res, int via) {
+			const uint32_t code = res == 1 ? GA_MOVE_LEFT : res == 2 ? GA_MOVE_DIAG : GA_MOVE_UP;
+			pack |= (code | (res == 3 ? 0u : ((uint32_t)via << 2))) << (8 * (len & 3));
+			if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * 64] = pack; pack = 0; }
+			len++;
+		};
+		auto baseAt = [&](uint64_t col) -> int {
+			if (!(col >= bwCol0 && col < bwCol0 + 32))
+			{
+				uint64_t wi = col >> 4;
+				wi = wi > 0 ? wi - 1 : 0;
+				bwCol0 = wi * 16;
+				bw = (uint64_t)g.seq2[wi] | ((uint64_t)g.seq2[wi + 1] << 32);
+			}
+			return (int)(bw >> (2 * (uint32_t)(col - bwCol0))) & 3;
+		};
+		// after a change of node or slice: where the node's columns are, its graph record; and the window, whenever it does not reach
+		// at least a few columns to the left of the current one
+		auto ensure = [&]() {
+			if (needSetup)
+			{
+				const int slot = find_in(l, tCN, (int)nN, node);
+				if (slot < 0) { status = GA_ASSERTION; tracing = false; return; }       // assert(slice.scores.hasNode(nodeIndex)) (:498)
+				slotRow = curRow + l.rd(tCB + slot);
+				wLo = 1; wHi = 0;
+			}
+			const bool refill = !(offset >= wLo && offset <= wHi) || (wLo > 0 && offset - wLo < 4);
+			const uint32_t nLo = offset >= (uint32_t)(kWin - 1) ? offset - (uint32_t)(kWin - 1) : 0;
+			Col wc[kWin];
+			if (refill)
+			{
+#pragma unroll
+				for (int i = 0; i < kWin; i++) { uint32_t ew; wc[i].vp = 0; wc[i].vn = 0; wc[i].before = 0; if (nLo + (uint32_t)i <= offset) rec_load<8>(m, slotRow + nLo + (uint32_t)i, wc[i], ew); }
+			}
+			if (needSetup && node != recNode)
+			{
+				const uint32_t* rec = g_rec(g, node);
+				firstCol = ((uint64_t)rec[1] << 32) | rec[0];
+				inDeg = rec[3] & 0xffffu;
+#pragma unroll
+				for (int k = 0; k < 4; k++) { nb[k] = rec[8 + k]; nbLen[k] = rec[12 + k]; }
+				recNode = node;
+			}
+			needSetup = false;
+			if (refill)
+			{
+				wLo = nLo; wHi = offset;
+#pragma unroll
+				for (int i = 0; i < kWin; i++)
 				{
-					if (diagonal < here) return -1;
-					if (diagonal == here) { node = un; offset = uo; row = row - 1; return 2; }
+					if (wLo + (uint32_t)i <= wHi)
+					{
+						const int at = tWIN + i * 5;
+						l.wr(at, (uint32_t)wc[i].vp); l.wr(at + 1, (uint32_t)(wc[i].vp >> 32)); l.wr(at + 2, (uint32_t)wc[i].vn); l.wr(at + 3, (uint32_t)(wc[i].vn >> 32)); l.wr(at + 4, (uint32_t)wc[i].before);
+					}
+				}
+			}
+			winRead(offset, q0);
+			if (offset > wLo) winRead(offset - 1, q1);
+		};
+		ensure();
+#ifdef GA_EMULATE
+#define GAL_ANY(x) (x)
+#else
+#define GAL_ANY(x) (__ballot(x) != 0)
+#endif
+		uint64_t lapT = lap_clock();
+		while (GAL_ANY(tracing))
+		{
+			{ const uint64_t t2 = lap_clock(); st.laps[1] += t2 - lapT; lapT = t2; }
+			// ---- fast steps: inside the node (offset > 0), inside the slice (r > 0), both columns in the window ----
+			while (true)
+			{
+				const int r = (int)(row - sIdx * W);
+				const bool fast = tracing && r > 0 && offset > wLo && offset <= wHi && len + 8 < L.cap_moves;
+				if (!GAL_ANY(fast)) break;
+				if (fast)
+				{
+					const uint64_t mR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull, mU = ~(~0ull << r);      // rows 0 .. r, rows 0 .. r - 1
+					const int here = q0.before + __builtin_popcountll(q0.vp & mR) - __builtin_popcountll(q0.vn & mR);
+					const int horizontal = q1.before + __builtin_popcountll(q1.vp & mR) - __builtin_popcountll(q1.vn & mR);
+					const int base = baseAt(firstCol + offset);
+					const bool match = ((e[base] >> r) & 1) != 0;
+					int res;
+					if (horizontal < here - 1) res = -1;
+					else if (horizontal == here - 1) res = 1;
+					else
+					{
+						const int diagonal = q1.before + __builtin_popcountll(q1.vp & mU) - __builtin_popcountll(q1.vn & mU);
+						const int want = match ? here : here - 1;
+						res = diagonal < want ? -1 : diagonal == want ? 2 : 0;
+					}
+					if (res == 0)
+					{
+						const int up = q0.before + __builtin_popcountll(q0.vp & mU) - __builtin_popcountll(q0.vn & mU);
+						res = up == here - 1 ? 3 : -1;                           // assert(false) (:588)
+					}
+					if (res < 0) { status = GA_ASSERTION; tracing = false; }
+					else
+					{
+						if (res >= 2) row = row - 1;
+						if (res != 3)
+						{
+							offset -= 1;
+							q0 = q1;
+							if (offset > wLo) winRead(offset - 1, q1);
+						}
+						putMove(res, 0);
+					}
+				}
+			}
+			{ const uint64_t t2 = lap_clock(); st.laps[0] += t2 - lapT; lapT = t2; }
+			// ---- the general step, for every lane still tracing (none of them can take a fast step) ----
+			if (tracing)
+			{
+				if (row == 0xffffffffu) { tracing = false; continue; }               // reached the row before the first one
+				if (len + 8 >= L.cap_moves) { status = GA_CAP_TRACE; tracing = false; continue; }
+				if (inDeg > 4) { status = GA_PUNT; tracing = false; continue; }
+				if (!(offset >= wLo && offset <= wHi && (offset == 0 || offset > wLo))) { ensure(); if (!tracing) continue; }
+				const int r = (int)(row - sIdx * W);
+				const int here = col_value(q0.vp, q0.vn, q0.before, r);
+				if (row == 0 && node == st.seedNode && (here == 0 || here == 1)) { row = 0xffffffffu; tracing = false; continue; }     // free start (:500)
+				const int base = baseAt(firstCol + offset);
+				const bool match = ((e[base] >> r) & 1) != 0;
+				int res = 0, via = 0;
+				const uint32_t curNode = node, curOffset = offset;
+				auto decide = [&](int horizontal, int diagonal, uint32_t un, uint32_t uo) -> int {
+					if (horizontal < here - 1) return -1;
+					if (horizontal == here - 1) { node = un; offset = uo; return 1; }
+					if (match)
+					{
+						if (diagonal < here) return -1;
+						if (diagonal == here) { node = un; offset = uo; row = row - 1; return 2; }
+					}
+					else
+					{
+						if (diagonal < here - 1) return -1;
+						if (diagonal == here - 1) { node = un; offset = uo; row = row - 1; return 2; }
+					}
+					return 0;
+				};
+				// value in the last row of the slice above (the all-zero seed slice before slice 0) of column (n, o)
+				auto valueAbove = [&](uint32_t n, uint32_t o) -> int {
+					if (sIdx == 0) return n == st.seedNode ? 0 : big;
+					Col c;
+					if (!recordIn(tPN, tPB, pN, prvRow, n, o, c)) return big;
+					return col_value(c.vp, c.vn, c.before, W - 1);
+				};
+				if (curOffset == 0)
+				{
+					// the last columns of the in-neighbours in this slice: requested together, looked at in the reference's order
+					Col nc[4];
+					bool nIn[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++) { nIn[k] = false; nc[k].vp = 0; nc[k].vn = 0; nc[k].before = 0; if ((uint32_t)k < inDeg) nIn[k] = recordIn(tCN, tCB, nN, curRow, nb[k], nbLen[k] - 1, nc[k]); }
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+					{
+						if ((uint32_t)k < inDeg && res == 0)
+						{
+							const uint32_t mo = nbLen[k] - 1;
+							via = k;
+							const int horizontal = nIn[k] ? col_value(nc[k].vp, nc[k].vn, nc[k].before, r) : big;
+							int diagonal = 0;
+							if (horizontal > here - 1) diagonal = r > 0 ? (nIn[k] ? col_value(nc[k].vp, nc[k].vn, nc[k].before, r - 1) : big) : valueAbove(nb[k], mo);
+							res = decide(horizontal, diagonal, nb[k], mo);
+						}
+					}
+					if (res == 1 || res == 2) needSetup = true;                        // entered another node
 				}
 				else
 				{
-					if (diagonal < here - 1) return -1;
-					if (diagonal == here - 1) { node = un; offset = uo; row = row - 1; return 2; }
-				}
-				return 0;
-			};
-			// value one row up in column (n, o): this slice for r > 0, the slice above (its row 63) for r == 0, the all-zero seed slice before slice 0
-			auto valueUp = [&](uint32_t n, uint32_t o) -> int {
-				if (r > 0) return valueIn(tCN, tCB, nN, curRow, n, o, r - 1);
-				if (sIdx == 0) return n == st.seedNode ? 0 : big;
-				return valueIn(tPN, tPB, pN, prvRow, n, o, W - 1);
-			};
-			if (curOffset == 0)
-			{
-				const uint32_t inDeg = rec[3] & 0xffffu;
-				for (uint32_t k = 0; k < inDeg && res == 0; k++)
-				{
-					const uint32_t nb = inDeg <= 4 ? rec[8 + k] : g.in_nbr[g.in_off[curNode] + k];
-					const uint32_t mo = (inDeg <= 4 ? rec[12 + k] : g_rec(g, nb)[2]) - 1;
-					via = (int)k;
-					const int horizontal = valueIn(tCN, tCB, nN, curRow, nb, mo, r);
+					const int horizontal = col_value(q1.vp, q1.vn, q1.before, r);
 					int diagonal = 0;
-					if (horizontal > here - 1) diagonal = valueUp(nb, mo);
-					res = decide(horizontal, diagonal, nb, mo);
+					if (horizontal > here - 1) diagonal = r > 0 ? col_value(q1.vp, q1.vn, q1.before, r - 1) : valueAbove(curNode, curOffset - 1);
+					res = decide(horizontal, diagonal, curNode, curOffset - 1);
 				}
-			}
-			else
-			{
-				Col lc; uint32_t lew;
-				rec_load<R>(m, colRow - 1, lc, lew);
-				const int horizontal = col_value(lc.vp, lc.vn, lc.before, r);
-				int diagonal = 0;
-				if (horizontal > here - 1) diagonal = r > 0 ? col_value(lc.vp, lc.vn, lc.before, r - 1) : valueUp(curNode, curOffset - 1);
-				res = decide(horizontal, diagonal, curNode, curOffset - 1);
-			}
-			if (res < 0) { status = GA_ASSERTION; break; }
-			if (res == 0)
-			{
-				const int up = r > 0 ? col_value(c.vp, c.vn, c.before, r - 1) : valueUp(curNode, curOffset);
-				if (up != here - 1) { status = GA_ASSERTION; break; }              // assert(false) (:588)
-				row = row - 1;
-				res = 3;
-			}
-			// put the move away (the step onto the row before the first one is not part of the trace, :949-950)
-			if (row != 0xffffffffu)
-			{
-				if (via > 62) { status = GA_CAP_TRACE; break; }
-				const uint32_t code = res == 1 ? GA_MOVE_LEFT : res == 2 ? GA_MOVE_DIAG : GA_MOVE_UP;
-				pack |= (code | (res == 3 ? 0u : ((uint32_t)via << 2))) << (8 * (len & 3));
-				if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * 64] = pack; pack = 0; }
-				len++;
-			}
-			if (res >= 2 && r == 0 && row != 0xffffffffu)
-			{
-				// stepped into the slice above
-				sIdx--;
-				int t = tCN; tCN = tPN; tPN = t;
-				t = tCB; tCB = tPB; tPB = t;
-				nN = pN; curRow = prvRow;
-				if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN, prvRow);
-				loadEq(sIdx);
+				if (res < 0) { status = GA_ASSERTION; tracing = false; continue; }
+				if (res == 0)
+				{
+					const int up = r > 0 ? col_value(q0.vp, q0.vn, q0.before, r - 1) : valueAbove(curNode, curOffset);
+					if (up != here - 1) { status = GA_ASSERTION; tracing = false; continue; }              // assert(false) (:588)
+					row = row - 1;
+					res = 3;
+				}
+				// put the move away (the step onto the row before the first one is not part of the trace, :949-950)
+				if (row == 0xffffffffu) { tracing = false; continue; }
+				putMove(res, via);
+				if (res >= 2 && r == 0)
+				{
+					// stepped into the slice above
+					sIdx--;
+					int t = tCN; tCN = tPN; tPN = t;
+					t = tCB; tCB = tPB; tPB = t;
+					nN = pN; curRow = prvRow;
+					pN = aN; prvRow = aRow;
+					if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN);
+					if (sIdx > 1) loadHeader(sIdx - 2, aN, aRow);
+					loadEq(sIdx);
+					needSetup = true;
+				}
+				ensure();
 			}
 		}
+#undef GAL_ANY
+		{ const uint64_t t2 = lap_clock(); st.laps[1] += t2 - lapT; lapT = t2; }
 		if (len & 3) m.moves[(uint64_t)(len >> 2) * 64] = pack;
+		st.laps[3] = lap_clock();
 		// hand the moves over: claim `len` bytes (rounded to words) of the pool and copy them
 		if (status == GA_OK)
 		{
@@ -889,12 +1205,20 @@ template <int N, int R> GAL_FN void lane_finish(const GaLanesLaunch& L, const La
 			else
 			{
 				uint32_t* dst = (uint32_t*)(L.traces + at);
-				for (uint32_t k = 0; k < words; k++) dst[k] = m.moves[(uint64_t)k * 64];
+				for (uint32_t k = 0; k < words; k += 8)
+				{
+					uint32_t a[8];
+#pragma unroll
+					for (int i = 0; i < 8; i++) a[i] = m.moves[(uint64_t)(k + (uint32_t)i) * 64];     // (the staging plane has a row of slack past `words`)
+#pragma unroll
+					for (int i = 0; i < 8; i++) if (k + (uint32_t)i < words) dst[k + (uint32_t)i] = a[i];
+				}
 				out.trace_off = at;
 				out.trace_len = len;
 			}
 		}
 	}
+	{ const uint64_t t2 = lap_clock(); st.laps[2] += t2 - st.laps[3]; }
 	out.status = status;
 	if (status != GA_OK) { out.n_valid = 0; out.score = 0x7fffffff; out.trace_len = 0; }
 	L.outs[st.job] = out;

@@ -95,6 +95,8 @@ inline VU load_lanes_u64(const uint64_t* p, int count) { VU r; for (int i = 0; i
 // per-lane indexed load / masked indexed store
 template <typename T> inline VI gather(const T* p, const VI& idx) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)p[idx.v[i]]; return r; }
 inline VU gather64(const uint64_t* p, const VI& idx) { VU r; for (int i = 0; i < LANES; i++) r.v[i] = p[idx.v[i]]; return r; }
+// word `word` of the 16-word record of element idx (64-bit addressing: idx is an unsigned 32-bit element number)
+inline VI gather_rec(const uint32_t* p, const VI& idx, int word) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)p[(uint64_t)(uint32_t)idx.v[i] * 16 + (uint32_t)word]; return r; }
 template <typename T> inline void scatter(T* p, const VI& idx, const VI& x, const VB& m) { for (int i = 0; i < LANES; i++) if (m.v[i]) p[idx.v[i]] = (T)x.v[i]; }
 // a value every lane holds identically, handed to the scalar unit
 inline int wave_uniform(int x) { return x; }
@@ -170,6 +172,7 @@ GA_FN void store_lanes(uint64_t* p, int count, VU x) { if ((int)threadIdx.x < co
 GA_FN VU load_lanes_u64(const uint64_t* p, int count) { return (int)threadIdx.x < count ? p[threadIdx.x] : 0ull; }
 template <typename T> GA_FN VI gather(const T* p, VI idx) { return (int)p[idx]; }
 GA_FN VU gather64(const uint64_t* p, VI idx) { return p[idx]; }
+GA_FN VI gather_rec(const uint32_t* p, VI idx, int word) { return (int)p[(uint64_t)(uint32_t)idx * 16 + (uint32_t)word]; }
 template <typename T> GA_FN void scatter(T* p, VI idx, VI x, VB m) { if (m) p[idx] = (T)x; }
 // one wave per workgroup: orders this wave's LDS / global traffic (s_waitcnt + s_barrier)
 GA_FN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

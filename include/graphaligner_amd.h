@@ -145,12 +145,15 @@ typedef struct ga_batch_stats {
 	uint64_t n_jobs;             /* extension jobs (read directions) */
 	uint64_t column_updates;     /* sum over jobs of band columns computed (unit of work) */
 	uint64_t slices;             /* 64-row slices computed */
-	uint64_t jobs_retried;       /* jobs rerun with the wide-band kernel variant */
-	double kernel_ms;            /* HIP-event time of the extension kernel(s) of the last ga_batch_run */
+	uint64_t jobs_retried;       /* jobs the first pass handed to the wave-per-read kernel ladder */
+	double kernel_ms;            /* HIP-event time of the extension kernel(s) of the last ga_batch_run, all passes */
 	double prep_kernel_ms;       /* HIP-event time of the read-coding kernel */
 	uint32_t slots, waves_per_cu;
 	uint64_t scratch_bytes;
 	uint64_t stamps[8];          /* diagnostic builds (GA_STAMPS) only: shader cycles per phase, summed over jobs */
+	double main_kernel_ms;       /* HIP-event time of the first pass alone (the lanes = reads kernel over all jobs) */
+	int32_t main_variant;        /* its variant: band nodes per lane * 1000 + record block * 10 + (1 when 32 lanes per wave); 0 = none */
+	int32_t reserved;
 } ga_batch_stats_t;
 int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out);
 

@@ -60,7 +60,7 @@ struct EmulBatch : GaBackendBatch
 
 	// the lanes = reads program (ga_lanes.h): a wave's 64 lanes are run one after the other through each phase; the points
 	// where the real wave decides something together (any lane still live, the slice's row range) sit between the phases
-	template <int N, int R> void runLanesGroup(const std::vector<uint32_t>& group, uint32_t capCols, uint32_t capRows, uint32_t capMoves)
+	template <int N> void runLanesGroup(const std::vector<uint32_t>& group, uint32_t capCols, uint32_t capRows, uint32_t capMoves)
 	{
 		using namespace gal;
 		GaLanesLaunch L;
@@ -86,33 +86,25 @@ struct EmulBatch : GaBackendBatch
 			m.snodes = (uint32_t*)(scratch.data() + lay.snodes) + lane;
 			m.moves = (uint32_t*)(scratch.data() + lay.moves) + lane;
 			m.arena = scratch.data() + lay.arena;
+			m.stage = nullptr;
 			const bool has = lane < (int)group.size();
 			lane_begin<N>(L, m, st[lane], has ? group[lane] : 0, has);
 		}
-		uint32_t rowTop = 0;
+		// (on the device one arena row belongs to one step of the wave; a lane run on its own simply counts its own steps)
+		std::vector<uint32_t> rowTop(64, 0);
 		for (uint32_t slice = 0; ; slice++)
 		{
 			bool any = false;
-			uint32_t maxCols = 0;
 			for (int lane = 0; lane < 64; lane++)
 			{
 				lane_band<N>(L, mem[lane], st[lane], slice);
 				any = any || st[lane].live;
-				maxCols = std::max(maxCols, st[lane].totalCols);
 			}
 			if (!any) break;
-			const bool fits = rowTop + maxCols <= L.cap_rows;
-			for (int lane = 0; lane < 64; lane++)
-			{
-				if (!fits && st[lane].live) { st[lane].status = GA_CAP_ARENA; st[lane].live = false; }
-				st[lane].rowBase = rowTop;
-			}
-			if (!fits) break;
-			rowTop += maxCols;
-			for (int lane = 0; lane < 64; lane++) fill_slice<N, R>(L.graph, mem[lane], st[lane], slice, st[lane].live);
+			for (int lane = 0; lane < 64; lane++) fill_slice<N, 8>(L.graph, mem[lane], st[lane], slice, st[lane].live, rowTop[lane], L.cap_rows, L.cap_cols);
 			for (int lane = 0; lane < 64; lane++) lane_end_slice<N>(L, mem[lane], st[lane], slice);
 		}
-		for (int lane = 0; lane < 64; lane++) lane_finish<N, R>(L, mem[lane], st[lane], lane < (int)group.size());
+		for (int lane = 0; lane < 64; lane++) lane_finish<N>(L, mem[lane], st[lane], lane < (int)group.size());
 	}
 
 	int run() override
@@ -139,9 +131,9 @@ struct EmulBatch : GaBackendBatch
 					std::vector<uint32_t> group(order.begin() + at, order.begin() + std::min(order.size(), at + 64));
 					const uint32_t maxRows = jobs[group[0]].n_rows;
 					const uint32_t capRows = (maxRows / 64) * (pass == 0 ? 600 : 2500) + 64, capMoves = maxRows * (pass == 0 ? 2 : 3) + 512;
-					if (pass == 0) { if ((at / 64) % 2 == 0) runLanesGroup<16, 2>(group, 2048, capRows, capMoves); else runLanesGroup<16, 1>(group, 2048, capRows, capMoves); }
-					else if (pass == 1) runLanesGroup<32, 4>(group, 4096, capRows, capMoves);
-					else runLanesGroup<64, 8>(group, 8192, capRows, capMoves);
+					if (pass == 0) runLanesGroup<10>(group, 2048, capRows, capMoves);
+					else if (pass == 1) runLanesGroup<24>(group, 4096, capRows, capMoves);
+					else runLanesGroup<56>(group, 8192, capRows, capMoves);
 				}
 				std::vector<uint32_t> again;
 				for (uint32_t j : order) if (outs[j].status == GA_CAP_NODES || outs[j].status == GA_CAP_HEAP || outs[j].status == GA_CAP_COLS || outs[j].status == GA_CAP_ARENA || outs[j].status == GA_CAP_TRACE) again.push_back(j);

@@ -1,0 +1,34 @@
+# counters of the lanes = reads kernel on the benchmark batch: instruction mix, busy / wait cycles, HBM traffic, L2 hits
+# (each --pmc set is its own run; no tracing domains next to counters).  usage on the GPU box: bash tools/pmc_lanes.sh [bench args]
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+O=gpurun_out/pmc_lanes
+rm -rf $O && mkdir -p $O
+run() { name=$1; shift; pmc=$1; shift
+  rocprofv3 --pmc $pmc --output-format csv -d $O/$name -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 "$@" > $O/$name.json 2> $O/$name.err; echo "$name done"; }
+run a "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "$@"
+run b "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES" "$@"
+run fetch "FETCH_SIZE" "$@"
+run write "WRITE_SIZE" "$@"
+run tcc "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "$@"
+run grbm "GRBM_GUI_ACTIVE" "$@"
+python3 - <<PY
+import csv, glob, json
+out = {}
+for d in ('a', 'b', 'fetch', 'write', 'tcc', 'grbm'):
+    fs = glob.glob('$O/%s/*/*_counter_collection.csv' % d)
+    if not fs: continue
+    for r in csv.DictReader(open(fs[0])):
+        if 'ga_lanes_kernel' in r['Kernel_Name']:
+            out[r['Counter_Name']] = out.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+b = json.loads(open('$O/a.json').read().strip().splitlines()[-1])
+cols = b['roofline']['column_updates_per_launch']
+out['column_updates'] = cols
+out['kernel_ms_under_counters'] = b['roofline']['kernel_ms']
+if 'FETCH_SIZE' in out: out['hbm_read_bytes_uncorrected'] = out['FETCH_SIZE'] * 1024
+if 'WRITE_SIZE' in out: out['hbm_write_bytes'] = out['WRITE_SIZE'] * 1024
+out['per_column_update'] = {k: round(v / cols, 3) for k, v in out.items() if k.startswith('SQ_') or k.startswith('TCC')}
+json.dump(out, open('$O/summary.json', 'w'), indent=1)
+print(json.dumps(out, indent=1))
+PY

@@ -94,16 +94,15 @@ __global__ void __launch_bounds__(64) k_fill_pf(const uint32_t* __restrict__ seq
 		const int cn = last ? 0 : c + U;
 		for (int i = 0; i < U; i++) nxt[i] = src[(size_t)(cn + i) * 64 + lane];
 		bnxt = (uint64_t)seq2[(gcol + U) >> 4] | ((uint64_t)seq2[((gcol + U) >> 4) + 1] << 32);
+#pragma unroll
 		for (int i = 0; i < U; i++)
 		{
 			const int b = (int)(bcur >> (((gcol & 15) + i) * 2)) & 3;
 			const uint32_t pe = cur[i];
 			int calc = before + 1;
 			const int above = (int)(pe >> 3) + before - 3;
-			int d = 0;
-			if (calc > above && (pe & 4)) { d = calc - above; d = d > 2 ? 2 : d; }
-			const int flags = b | ((pe & 8) ? 4 : 0) | (d << 3);
-			bitvector_column_step(vp, vn, before, calc, flags, e0, e1, e2, e3);
+			const bool re = calc > above && (pe & 4);
+			bitvector_column_step(vp, vn, before, re ? above : calc, b | ((pe & 8) ? 4 : 0), e0, e1, e2, e3);
 			const int end = before + __builtin_popcountll(vp) - __builtin_popcountll(vn);
 			const uint32_t ew = ((uint32_t)end << 3) | (uint32_t)(vp >> 63) | ((uint32_t)(vn >> 63) << 1);
 			uint8_t* rec = my + rec_off<R>(row, lane);
@@ -112,6 +111,79 @@ __global__ void __launch_bounds__(64) k_fill_pf(const uint32_t* __restrict__ seq
 			endCur[(size_t)(c + i) * 64 + lane] = ew;
 			row++;
 		}
+		gcol += U;
+		c += U;
+		if (c == colsPerSlice)
+		{
+			c = 0;
+			uint32_t* t = endPrev; endPrev = endCur; endCur = t;
+			e0 = e0 * 0x9E3779B97F4A7C15ull + 1; e1 ^= e0 >> 7; e2 += e1; e3 ^= e2 << 3;
+		}
+		for (int i = 0; i < U; i++) cur[i] = nxt[i];
+		bcur = bnxt;
+	}
+}
+
+// the prefetched loop with the records staged in LDS and written out cooperatively: every 8 steps the wave's 8 x 64 records
+// (12 KB, blocks of 8 columns per lane = the R = 8 layout) leave as twelve fully coalesced 1 KB stores
+template <int U>
+__global__ void __launch_bounds__(64) k_fill_staged(const uint32_t* __restrict__ seq2, size_t genomeWords, const uint64_t* __restrict__ eqTab,
+                                              uint8_t* __restrict__ arena, size_t arenaBytesPerWave, uint32_t* __restrict__ endBuf, int steps, int colsPerSlice)
+{
+	__shared__ uint64_t stage[64 * 25];          // lane stride 200 B (25 x 8): conflict-free 8-byte writes
+	const int lane = threadIdx.x;
+	const size_t blk = blockIdx.x;
+	uint8_t* my = arena + blk * arenaBytesPerWave;
+	uint32_t* endPrev = endBuf + blk * 2 * (size_t)colsPerSlice * 64;
+	uint32_t* endCur = endPrev + (size_t)colsPerSlice * 64;
+	uint64_t e0 = eqTab[(blk * 4 + 0) * 64 + lane], e1 = eqTab[(blk * 4 + 1) * 64 + lane], e2 = eqTab[(blk * 4 + 2) * 64 + lane], e3 = eqTab[(blk * 4 + 3) * 64 + lane];
+	uint64_t vp = ~0ull, vn = 0;
+	int before = 1000 + lane;
+	size_t gcol = ((size_t)(blk * 64 + lane) * 7919u * 64u) % (genomeWords * 16 - (size_t)steps - 64);
+	uint32_t row = 0;
+	int c = 0;
+	uint32_t cur[U], nxt[U];
+	uint64_t bcur, bnxt;
+	for (int i = 0; i < U; i++) cur[i] = endPrev[(size_t)(c + i) * 64 + lane];
+	bcur = (uint64_t)seq2[gcol >> 4] | ((uint64_t)seq2[(gcol >> 4) + 1] << 32);
+	for (int k = 0; k < steps; k += U)
+	{
+		const bool last = c + U == colsPerSlice;
+		const uint32_t* src = last ? endCur : endPrev;
+		const int cn = last ? 0 : c + U;
+		for (int i = 0; i < U; i++) nxt[i] = src[(size_t)(cn + i) * 64 + lane];
+		bnxt = (uint64_t)seq2[(gcol + U) >> 4] | ((uint64_t)seq2[((gcol + U) >> 4) + 1] << 32);
+#pragma unroll
+		for (int i = 0; i < U; i++)
+		{
+			const int b = (int)(bcur >> (((gcol & 15) + i) * 2)) & 3;
+			const uint32_t pe = cur[i];
+			int calc = before + 1;
+			const int above = (int)(pe >> 3) + before - 3;
+			const bool re = calc > above && (pe & 4);
+			const uint64_t eq0 = (b & 2) ? ((b & 1) ? e3 : e2) : ((b & 1) ? e1 : e0);
+			bitvector_column_step(vp, vn, before, re ? above : calc, b | ((pe & 8) ? 4 : 0), e0, e1, e2, e3);
+			(void)eq0;
+			const int end = before + __builtin_popcountll(vp) - __builtin_popcountll(vn);
+			const uint32_t ew = ((uint32_t)end << 3) | (uint32_t)(vp >> 63) | ((uint32_t)(vn >> 63) << 1);
+			uint64_t* st = stage + lane * 25 + i * 3;
+			st[0] = vp; st[1] = vn; st[2] = (uint64_t)(uint32_t)before | ((uint64_t)ew << 32);
+			endCur[(size_t)(c + i) * 64 + lane] = ew;
+		}
+		// cooperative write of the 8-row block: chunk q (16 B) of the 12 KB image belongs to lane q / 12
+		__builtin_amdgcn_wave_barrier();
+		uint8_t* dst = my + (size_t)(row / 8) * (64 * 192);
+#pragma unroll
+		for (int j = 0; j < 12; j++)
+		{
+			const uint32_t q = (uint32_t)lane + 64u * j;
+			const uint32_t ln = q / 12u, part = q % 12u;
+			const uint64_t* sp = stage + ln * 25 + part * 2;
+			const uint64_t a = sp[0], bq = sp[1];
+			*(uint4*)(dst + (size_t)q * 16) = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)bq, (uint32_t)(bq >> 32));
+		}
+		__builtin_amdgcn_wave_barrier();
+		row += U;
 		gcol += U;
 		c += U;
 		if (c == colsPerSlice)
@@ -185,6 +257,20 @@ template <int R, int LANES> int run(int cus, const uint32_t* seq2, size_t genome
 	}
 	printf("R=%d lanes/wave=%2d waves=%4d: PREFETCHED fill %8.3f ms = %6.1f G/s, %6.1f GB/s at 28 B (%.1f %% of 8 TB/s), %.0f cycles per wave step at 2.4 GHz\n",
 	       R, LANES, waves, bestP, (double)nReads * steps / bestP / 1e6, (double)nReads * steps * 28 / bestP / 1e6, (double)nReads * steps * 28 / bestP / 1e6 / 80.0, bestP * 1e-3 * 2.4e9 / steps);
+	if (LANES == 64 && R == 8)
+	{
+		float bestS = 1e30f;
+		for (int rep = 0; rep < 3; rep++)
+		{
+			OK(hipEventRecord(a, 0));
+			hipLaunchKernelGGL((k_fill_staged<8>), dim3(waves), dim3(64), 0, 0, seq2, genomeWords, eqTab, arena, arenaBytesPerWave, endBuf, steps, colsPerSlice);
+			OK(hipEventRecord(b, 0));
+			OK(hipEventSynchronize(b));
+			float ms = 0; OK(hipEventElapsedTime(&ms, a, b));
+			bestS = ms < bestS ? ms : bestS;
+		}
+		printf("R=8 via LDS staging, coalesced block writes, unrolled steps: %8.3f ms = %.0f cycles per wave step at 2.4 GHz\n", bestS, bestS * 1e-3 * 2.4e9 / steps);
+	}
 	if (LANES == 64)
 		for (int rep = 0; rep < 2; rep++)
 		{
