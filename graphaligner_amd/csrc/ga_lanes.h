@@ -975,7 +975,8 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		bool needSetup = true;
 		uint32_t slotRow = 0, recNode = 0xffffffffu, inDeg = 0;
 		uint32_t nb[4] = {0, 0, 0, 0}, nbLen[4] = {0, 0, 0, 0};
-		uint64_t firstCol = 0, bw = 0, bwCol0 = ~0ull;
+		uint64_t firstCol = 0;
+		uint32_t wbases = 0;                          // the graph bases of the window's columns, 2 bits each from wLo up
 		uint32_t wLo = 1, wHi = 0;                    // columns of `node` (in slice sIdx) the window holds: [wLo, wHi], empty when wLo > wHi
 		bool tracing = true;
 		auto winRead = [&](uint32_t o, Col& c) {
@@ -989,16 +990,6 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			pack |= (code | (res == 3 ? 0u : ((uint32_t)via << 2))) << (8 * (len & 3));
 			if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * 64] = pack; pack = 0; }
 			len++;
-		};
-		auto baseAt = [&](uint64_t col) -> int {
-			if (!(col >= bwCol0 && col < bwCol0 + 32))
-			{
-				uint64_t wi = col >> 4;
-				wi = wi > 0 ? wi - 1 : 0;
-				bwCol0 = wi * 16;
-				bw = (uint64_t)g.seq2[wi] | ((uint64_t)g.seq2[wi + 1] << 32);
-			}
-			return (int)(bw >> (2 * (uint32_t)(col - bwCol0))) & 3;
 		};
 		// after a change of node or slice: where the node's columns are, its graph record; and the window, whenever it does not reach
 		// at least a few columns to the left of the current one
@@ -1031,6 +1022,11 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			if (refill)
 			{
 				wLo = nLo; wHi = offset;
+				{
+					const uint64_t col = firstCol + wLo;
+					const uint32_t* q = g.seq2 + (col >> 4);
+					wbases = (uint32_t)(((uint64_t)q[0] | ((uint64_t)q[1] << 32)) >> (2 * (uint32_t)(col & 15)));
+				}
 #pragma unroll
 				for (int i = 0; i < kWin; i++)
 				{
@@ -1065,7 +1061,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					const uint64_t mR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull, mU = ~(~0ull << r);      // rows 0 .. r, rows 0 .. r - 1
 					const int here = q0.before + __builtin_popcountll(q0.vp & mR) - __builtin_popcountll(q0.vn & mR);
 					const int horizontal = q1.before + __builtin_popcountll(q1.vp & mR) - __builtin_popcountll(q1.vn & mR);
-					const int base = baseAt(firstCol + offset);
+					const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
 					const bool match = ((e[base] >> r) & 1) != 0;
 					int res;
 					if (horizontal < here - 1) res = -1;
@@ -1106,7 +1102,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				const int r = (int)(row - sIdx * W);
 				const int here = col_value(q0.vp, q0.vn, q0.before, r);
 				if (row == 0 && node == st.seedNode && (here == 0 || here == 1)) { row = 0xffffffffu; tracing = false; continue; }     // free start (:500)
-				const int base = baseAt(firstCol + offset);
+				const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
 				const bool match = ((e[base] >> r) & 1) != 0;
 				int res = 0, via = 0;
 				const uint32_t curNode = node, curOffset = offset;
