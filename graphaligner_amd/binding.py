@@ -263,5 +263,5 @@ def _unpack(R):
             t = R.trace[r.first_trace + k]
             tr[k] = (t.node_id, t.offset, t.reverse, t.read_pos, t.type, ord(t.graph_char), ord(t.read_char))
         reads.append(dict(status=r.status, failed=bool(r.failed), score=r.score, alignment_start=r.alignment_start, alignment_end=r.alignment_end,
-                          query_position=r.query_position, mappings=maps, trace=tr, columns=r.column_updates))
+                          query_position=r.query_position, mappings=maps, trace=tr, columns=r.column_updates, kernel_pass=r.reserved))
     return reads

@@ -176,6 +176,8 @@ struct DevBatch : GaBackendBatch
 	size_t dListCap = 0;
 	std::vector<GaJobOut> outs;
 	std::vector<uint32_t> orderHost;   // all jobs, longest first (the device queues hand them out in this order)
+	std::vector<uint8_t> passOf;       // which pass of the last run finished each job (0 = the first)
+	int passNo = 0;
 	GaRunStats st;
 	uint8_t* privateScratch = nullptr; // only when the graph's pool is taken by another batch
 	size_t privateBytes = 0;
@@ -287,6 +289,8 @@ struct DevBatch : GaBackendBatch
 	template <int N, int LW> int lanesPass(const std::vector<uint32_t>& list, uint32_t rowsPerSlice, bool first)
 	{
 		if (list.empty()) return 0;
+		for (uint32_t i : list) passOf[i] = (uint8_t)passNo;
+		passNo++;
 		gal::GaLanesLaunch P;
 		memset(&P, 0, sizeof(P));
 		P.graph = L.graph; P.hmm = L.hmm; P.eq = dEq; P.jobs = L.jobs; P.outs = L.outs;
@@ -332,6 +336,8 @@ struct DevBatch : GaBackendBatch
 		std::vector<uint32_t> again;
 		for (uint32_t i : orderHost) if ((takeCapacity && isCapacity(outs[i].status)) || (takeGeneral && needsGeneral(outs[i].status))) again.push_back(i);
 		if (again.empty()) return 0;
+		for (uint32_t i : again) passOf[i] = (uint8_t)passNo;
+		passNo++;
 		st.jobs_retried += again.size();
 		GaLaunch Rl = L;
 		uint32_t maxRows = 0;
@@ -369,6 +375,8 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipSetDevice(g->device));
 		st = GaRunStats();
 		outs.assign(jobs.size(), GaJobOut{});
+		passOf.assign(jobs.size(), 0);
+		passNo = 0;
 		if (jobs.empty()) return 0;
 		for (auto& o : outs) o.status = GA_NOT_RUN;
 		HIP_OK(hipMemcpyAsync(L.outs, outs.data(), outs.size() * sizeof(GaJobOut), hipMemcpyHostToDevice, stream));
@@ -416,6 +424,7 @@ struct DevBatch : GaBackendBatch
 	{
 		HIP_OK(hipSetDevice(g->device));
 		o = outs;
+		for (size_t i = 0; i < o.size(); i++) o[i].reserved2 = passOf[i];      // 0 = finished by the first pass
 		uint64_t top = 0;
 		HIP_OK(hipMemcpy(&top, L.trace_top, 8, hipMemcpyDeviceToHost));
 		top = std::min<uint64_t>(top, L.trace_pool_cap);

@@ -87,7 +87,7 @@ struct ga_graph
 	std::vector<uint64_t> nodeStart;
 	std::unordered_map<int64_t, uint32_t> lookup;
 	std::vector<int64_t> ids;
-	std::vector<std::vector<uint32_t>> in, out;
+	std::vector<std::pair<uint32_t, uint32_t>> edgeList;      // (from, to) node indices in the order the edges were added; the CSR lists are built at Finalize
 	std::vector<uint8_t> reverse;
 	std::vector<uint8_t> bases;         // 0..3, 4 for the dummy columns
 	GaFlatGraph flat;
@@ -97,12 +97,20 @@ struct ga_graph
 	ga_graph()
 	{
 		// dummy start node, one column (AlignmentGraph.cpp:22-30)
-		ids.push_back(0); nodeStart.push_back(0); in.emplace_back(); out.emplace_back(); reverse.push_back(0); bases.push_back(4);
+		ids.push_back(0); nodeStart.push_back(0); reverse.push_back(0); bases.push_back(4);
 	}
 	uint32_t nodeCount() const { return (uint32_t)nodeStart.size(); }
 	uint64_t nodeEnd(uint32_t n) const { return n + 1 == nodeStart.size() ? bases.size() : nodeStart[n + 1]; }
 	uint32_t nodeLen(uint32_t n) const { return (uint32_t)(nodeEnd(n) - nodeStart[n]); }
 	char baseChar(uint32_t node, uint32_t offset) const { uint8_t b = bases[nodeStart[node] + offset]; return b < 4 ? "ACGT"[b] : '-'; }
+	// neighbour lists in insertion order, without double edges (AlignmentGraph.cpp:104-105); valid once finalized
+	uint32_t inDegree(uint32_t n) const { return flat.in_off[n + 1] - flat.in_off[n]; }
+	uint32_t inNeighbor(uint32_t n, uint32_t k) const { return flat.in_nbr[flat.in_off[n] + k]; }
+	bool hasOutNeighbor(uint32_t n, uint32_t to) const
+	{
+		for (uint32_t e = flat.out_off[n]; e < flat.out_off[n + 1]; e++) if (flat.out_nbr[e] == to) return true;
+		return false;
+	}
 	int reverseNode(uint32_t n, uint32_t& outNode) const
 	{
 		// GetReverseNode (AlignmentGraph.cpp:199-214)
@@ -123,8 +131,6 @@ static int addNode(ga_graph* g, int64_t id, const char* seq, size_t len, bool re
 	g->lookup[id] = (uint32_t)g->nodeStart.size();
 	g->ids.push_back(id);
 	g->nodeStart.push_back(g->bases.size());
-	g->in.emplace_back();
-	g->out.emplace_back();
 	g->reverse.push_back(rev ? 1 : 0);
 	for (size_t i = 0; i < len; i++) g->bases.push_back(tables().baseCode[(uint8_t)seq[i]]);
 	return GA_S_OK;
@@ -135,10 +141,7 @@ static int addEdge(ga_graph* g, int64_t from, int64_t to)
 	if (g->finalized) return GA_E_INVALID;
 	auto f = g->lookup.find(from), t = g->lookup.find(to);
 	if (f == g->lookup.end() || t == g->lookup.end()) return GA_E_INVALID;
-	auto& inl = g->in[t->second];
-	auto& outl = g->out[f->second];
-	if (std::find(inl.begin(), inl.end(), f->second) == inl.end()) inl.push_back(f->second);      // no double edges (:104-105)
-	if (std::find(outl.begin(), outl.end(), t->second) == outl.end()) outl.push_back(t->second);
+	g->edgeList.emplace_back(f->second, t->second);                                               // double edges are dropped at Finalize (:104-105)
 	return GA_S_OK;
 }
 
@@ -154,7 +157,7 @@ static int finalizeGraph(ga_graph* g, int overlap)
 	if (g->finalized) return GA_E_INVALID;
 	g->dbgOverlap = overlap;
 	// dummy end node (AlignmentGraph.cpp:110-118)
-	g->ids.push_back(0); g->nodeStart.push_back(g->bases.size()); g->reverse.push_back(0); g->in.emplace_back(); g->out.emplace_back(); g->bases.push_back(4);
+	g->ids.push_back(0); g->nodeStart.push_back(g->bases.size()); g->reverse.push_back(0); g->bases.push_back(4);
 	g->finalized = true;
 	const uint32_t n = g->nodeCount();
 	GaFlatGraph& f = g->flat;
@@ -162,14 +165,39 @@ static int finalizeGraph(ga_graph* g, int overlap)
 	f.node_start.push_back(g->bases.size());
 	f.seq2.assign((g->bases.size() + 15) / 16 + 8, 0);      // (+ slack: the kernels request base words a little past a node's end)
 	for (size_t i = 0; i < g->bases.size(); i++) f.seq2[i >> 4] |= (uint32_t)(g->bases[i] & 3) << ((i & 15) * 2);
-	f.in_off.assign(n + 1, 0);
-	f.out_off.assign(n + 1, 0);
-	for (uint32_t i = 0; i < n; i++) { f.in_off[i + 1] = f.in_off[i] + (uint32_t)g->in[i].size(); f.out_off[i + 1] = f.out_off[i] + (uint32_t)g->out[i].size(); }
-	f.in_nbr.reserve(f.in_off[n] + 1);
-	f.out_nbr.reserve(f.out_off[n] + 1);
-	for (uint32_t i = 0; i < n; i++) { f.in_nbr.insert(f.in_nbr.end(), g->in[i].begin(), g->in[i].end()); f.out_nbr.insert(f.out_nbr.end(), g->out[i].begin(), g->out[i].end()); }
-	f.in_nbr.push_back(0);
-	f.out_nbr.push_back(0);
+	// neighbour lists: every node's in- and out-list in the order its edges were added, a repeated edge kept once (the reference
+	// checks std::find before every push_back, AlignmentGraph.cpp:104-105).  Counting sort by node, then per-node de-duplication.
+	{
+		const auto& E = g->edgeList;
+		std::vector<uint32_t> inCount(n + 1, 0), outCount(n + 1, 0);
+		for (const auto& e : E) { outCount[e.first + 1]++; inCount[e.second + 1]++; }
+		for (uint32_t i = 0; i < n; i++) { inCount[i + 1] += inCount[i]; outCount[i + 1] += outCount[i]; }
+		std::vector<uint32_t> inAll(E.size() + 1), outAll(E.size() + 1);
+		{
+			std::vector<uint32_t> inAt(inCount.begin(), inCount.end() - 1), outAt(outCount.begin(), outCount.end() - 1);
+			for (const auto& e : E) { outAll[outAt[e.first]++] = e.second; inAll[inAt[e.second]++] = e.first; }
+		}
+		auto compact = [&](const std::vector<uint32_t>& count, const std::vector<uint32_t>& all, std::vector<uint32_t>& off, std::vector<uint32_t>& nbr) {
+			off.assign(n + 1, 0);
+			nbr.clear();
+			nbr.reserve(all.size() + 1);
+			for (uint32_t i = 0; i < n; i++)
+			{
+				const size_t first = nbr.size();
+				for (uint32_t k = count[i]; k < count[i + 1]; k++)
+				{
+					bool seen = false;
+					for (size_t q = first; q < nbr.size(); q++) if (nbr[q] == all[k]) { seen = true; break; }
+					if (!seen) nbr.push_back(all[k]);
+				}
+				off[i + 1] = (uint32_t)nbr.size();
+			}
+			nbr.push_back(0);
+		};
+		compact(inCount, inAll, f.in_off, f.in_nbr);
+		compact(outCount, outAll, f.out_off, f.out_nbr);
+		std::vector<std::pair<uint32_t, uint32_t>>().swap(g->edgeList);
+	}
 	g->hmm = buildHmm();
 	return GA_S_OK;
 }
@@ -307,7 +335,7 @@ Partial mergePartials(const ga_graph& g, const Partial& first, const Partial& se
 	const ga_mapping_t& b = second.maps.front();
 	uint32_t an = g.lookup.at(a.node_id), bn = g.lookup.at(b.node_id);
 	if (a.node_id == b.node_id && a.is_reverse == b.is_reverse) startAt = 1;
-	else if (std::find(g.out[an].begin(), g.out[an].end(), bn) != g.out[an].end()) startAt = 0;
+	else if (g.hasOutNeighbor(an, bn)) startAt = 0;
 	for (size_t i = startAt; i < second.maps.size(); i++) { out.maps.push_back(second.maps[i]); out.seqs.push_back(second.seqs[i]); }
 	return out;
 }
@@ -332,8 +360,7 @@ bool traceItemsInner(const ga_graph& g, const std::string& seq, const Trace& tr,
 		bool diagonal = now.row != old.row;
 		if (sameColumn)
 		{
-			const auto& outs = g.out[now.node];
-			bool selfLoop = now.row == old.row + 1 && g.nodeLen(now.node) == 1 && std::find(outs.begin(), outs.end(), now.node) != outs.end();
+			bool selfLoop = now.row == old.row + 1 && g.nodeLen(now.node) == 1 && g.hasOutNeighbor(now.node, now.node);
 			if (!selfLoop) diagonal = false;
 		}
 		ga_trace_item_t it;
@@ -670,7 +697,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 				if (p.offset > 0) p.offset -= 1;
 				else
 				{
-					p.node = g.in[p.node][via];
+					p.node = g.inNeighbor(p.node, (uint32_t)via);
 					p.offset = g.nodeLen(p.node) - 1;
 				}
 			}

@@ -30,7 +30,7 @@ def random_genome(n, seed):
 class SynthGraph:
     """a variation graph over one backbone genome; node ids are 1.. in topological order"""
 
-    def __init__(self, genome, node_len=64, snp_every=0, indel_every=0, sv_every=0, seed=0, max_indel=20):
+    def __init__(self, genome, node_len=64, snp_every=0, indel_every=0, sv_every=0, seed=0, max_indel=20, first_id=1):
         self.genome = genome
         self.node_len = node_len
         rng = np.random.default_rng(seed)
@@ -65,7 +65,7 @@ class SynthGraph:
         self.edges = []          # (from, False, to, False)
         self.node_at = np.zeros(n, dtype=np.int32)     # backbone position -> node id (ref allele path)
         self.node_off = np.zeros(n, dtype=np.int32)    # offset inside that node
-        self._next_id = 1
+        self._next_id = first_id
         tails = []
 
         def add_chain(seq_bytes, tails_in, backbone_start=None):
@@ -117,6 +117,11 @@ class SynthGraph:
         for f, fs, t, te in self.edges:
             lines.append("L\t%d\t%s\t%d\t%s\t%dM" % (f, "-" if fs else "+", t, "-" if te else "+", overlap))
         return "\n".join(lines) + "\n"
+
+    def vg_bytes(self, chunk_nodes=1000):
+        """the graph as the reference's vg loader reads it (CommonUtils / stream.hpp:24-118): gzip-framed groups of vg.Graph messages,
+        chunks of at most `chunk_nodes` nodes, each chunk carrying the edges that leave its nodes"""
+        return vg_bytes(self.nodes, self.edges, chunk_nodes)
 
     # ---- haplotypes & reads -----------------------------------------------------------------------
     def haplotype_window(self, start, length, rng):
@@ -378,4 +383,98 @@ def walk_reads(graph, n_reads, length, sub=0.03, ins=0.03, dele=0.03, seed=1, bo
                 continue
             reads.append(np.concatenate([a, b]).tobytes().decode())
             seeds.append((int(path[k]), len(a), True))
+    return reads, seeds
+
+
+# ---- vg.Graph stream writer (for the chr22-like configuration; shares nothing with the library's decoder) ----------------
+def _varint(v):
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while True:
+        b = v & 0x7f
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _field(num, wire, payload):
+    return _varint((num << 3) | wire) + payload
+
+
+def vg_bytes(nodes, edges, chunk_nodes=1000):
+    """Graph{1: Node{1: sequence, 3: id}, 2: Edge{1: from, 2: to, 3: from_start, 4: to_end}} (vg.pb.h:149-173, 262-284),
+    framed as stream.hpp writes it: per group a gzip member holding varint count, then (varint length, message) * count"""
+    import gzip
+    by_from = {}
+    for e in edges:
+        by_from.setdefault(e[0], []).append(e)
+    members = []
+    for lo in range(0, len(nodes), chunk_nodes):
+        body = bytearray()
+        for nid, seq in nodes[lo:lo + chunk_nodes]:
+            sb = seq.encode() if isinstance(seq, str) else seq
+            msg = _field(1, 2, _varint(len(sb)) + sb) + _field(3, 0, _varint(nid))
+            body += _field(1, 2, _varint(len(msg)) + msg)
+        for nid, _ in nodes[lo:lo + chunk_nodes]:
+            for f, fs, t, te in by_from.get(nid, ()):
+                msg = _field(1, 0, _varint(f)) + _field(2, 0, _varint(t))
+                if fs:
+                    msg += _field(3, 0, _varint(1))
+                if te:
+                    msg += _field(4, 0, _varint(1))
+                body += _field(2, 2, _varint(len(msg)) + msg)
+        members.append(gzip.compress(_varint(1) + _varint(len(body)) + bytes(body), compresslevel=1))
+    return b"".join(members)
+
+
+# ---- several chromosomes (SURVEY.md C3: a 12.1 Mbp genome in 16 sequences) ---------------------------------------------------
+class MultiGraph:
+    """independent SynthGraphs with disjoint node id ranges, presented as one graph"""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.nodes = [n for p in parts for n in p.nodes]
+        self.edges = [e for p in parts for e in p.edges]
+
+    def gfa(self, overlap=0):
+        lines = ["H\tVN:Z:1.0"]
+        for nid, seq in self.nodes:
+            lines.append("S\t%d\t%s" % (nid, seq))
+        for f, fs, t, te in self.edges:
+            lines.append("L\t%d\t%s\t%d\t%s\t%dM" % (f, "-" if fs else "+", t, "-" if te else "+", overlap))
+        return "\n".join(lines) + "\n"
+
+    def vg_bytes(self, chunk_nodes=1000):
+        return vg_bytes(self.nodes, self.edges, chunk_nodes)
+
+
+def pangenome_graph(total_bp, chromosomes=16, node_len=64, seed=44, snp_every=100, indel_every=1000, sv_every=50000):
+    """yeast-like pangenome in `chromosomes` sequences of decreasing length"""
+    weights = np.linspace(1.6, 0.4, chromosomes)
+    lens = np.maximum(20000, (weights / weights.sum() * total_bp).astype(np.int64))
+    parts, first = [], 1
+    for c, n in enumerate(lens):
+        g = SynthGraph(random_genome(int(n), seed + 100 * c), node_len=node_len, snp_every=snp_every, indel_every=indel_every, sv_every=sv_every,
+                       seed=seed + 100 * c + 1, first_id=first)
+        first = g._next_id
+        parts.append(g)
+    return MultiGraph(parts)
+
+
+def simulate_reads_multi(mg, n_reads, length, seed=1, **kw):
+    """reads drawn from the chromosomes in proportion to their length"""
+    lens = np.array([len(p.genome) for p in mg.parts], dtype=np.float64)
+    share = np.maximum(1, np.round(lens / lens.sum() * n_reads).astype(np.int64))
+    while share.sum() > n_reads:
+        share[int(np.argmax(share))] -= 1
+    while share.sum() < n_reads:
+        share[int(np.argmax(lens))] += 1
+    reads, seeds = [], []
+    for c, (p, k) in enumerate(zip(mg.parts, share)):
+        r, s = simulate_reads(p, int(k), length, seed=seed + 7919 * c, **kw)
+        reads += r
+        seeds += s
     return reads, seeds

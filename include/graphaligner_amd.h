@@ -106,7 +106,7 @@ typedef struct ga_read_result {
 	int32_t status;          /* ga_status, per read */
 	int32_t failed;          /* AlignmentResult::alignmentFailed */
 	int32_t score;           /* vg::Alignment.score; INT32_MAX when failed */
-	int32_t reserved;
+	int32_t reserved;        /* diagnostic: 0 when the first kernel pass finished all of the read's extensions, else the number of the last pass that did */
 	uint64_t alignment_start, alignment_end, query_position;
 	uint64_t first_mapping, n_mappings;     /* into results->mappings */
 	uint64_t first_trace, n_trace;          /* into results->trace (empty unless requested) */
