@@ -12,7 +12,7 @@ With --gpus N every rank runs its own 50,000-read shard (different read seed) ag
 replicated in its GPU's HBM -- weak scaling, no collective on the data path.
 
 Prints ONE JSON line (rank 0): metric/value per the driver contract plus `roofline`
-(algorithmic 28 B per column update / live HIP-event kernel time vs 8 TB/s HBM) and
+(algorithmic 28 B per column update / live HIP-event time of the dominant kernel vs 8 TB/s HBM) and
 `cpu_baseline` (the CPU oracle, multi-threaded, on a bounded sample of the same reads).
 """
 import argparse
@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build with per-phase cycle stamps (not a timed build)")
     ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
-    ap.add_argument("--check", type=int, default=4, help="reads compared with the oracle after the run")
+    ap.add_argument("--check", type=int, default=64, help="reads compared with the oracle after the run (includes failed / later-pass reads)")
     args = ap.parse_args()
 
     import numpy as np
@@ -110,8 +110,10 @@ def main():
     t0 = time.time()
     lib_path = entry.build_stamped() if args.stamps else args.lib
     graph = binding.Graph(gfa=g.gfa(), device=local, lib_path=lib_path)
+    t_graph = time.time() - t0
+    t0 = time.time()
     batch = graph.prepare(reads, seeds, args.bandwidth, 0)
-    t_prep = time.time() - t0
+    t_prep_batch = time.time() - t0
     total_bp = batch.total_bp
 
     def barrier():
@@ -123,11 +125,13 @@ def main():
     for _ in range(args.warmup):
         batch.run()
     barrier()
-    kernel_ms = []
+    kernel_ms, main_kernel_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         batch.run()
-        kernel_ms.append(batch.stats()["kernel_ms"])
+        sk = batch.stats()
+        kernel_ms.append(sk["kernel_ms"])
+        main_kernel_ms.append(sk["main_kernel_ms"])
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -157,34 +161,51 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = aligned_total / (elapsed / args.steps) / 1e9
-    k_ms = float(np.mean(kernel_ms))
-    achieved = BYTES_PER_COLUMN_UPDATE * st["column_updates"] / (k_ms * 1e-3) / 1e9
-    # HBM traffic per launch: PMC counters cannot be read from inside this process, so the per-column-update
-    # figure measured with rocprofv3 --pmc on this kernel (profiles/r1_hbm_traffic.json) is scaled to this launch
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-    if os.path.exists(tpath):
-        traffic = int(json.load(open(tpath))["hbm_bytes_per_column_update"] * st["column_updates"])
+    k_ms = float(np.mean(kernel_ms))                   # all kernel passes of a step
+    main_ms = float(np.mean(main_kernel_ms))           # the dominant kernel alone: the first pass over all jobs
+    variant = int(st["main_variant"])
+    kernel_name = ("ga_lanes_kernel<%d,%d>" % (variant // 1000, 32 if variant % 10 else 64)) if variant else "ga_extend_kernel<64,false>"
+    dom_ms = main_ms if variant else k_ms
+    achieved = BYTES_PER_COLUMN_UPDATE * st["column_updates"] / (dom_ms * 1e-3) / 1e9
+    # HBM traffic per launch: PMC counters cannot be read from inside this process, so the per-column-update figure measured with
+    # rocprofv3 --pmc on this kernel and this workload (tools/pmc_lanes.sh -> profiles/r2_hbm_traffic.json) is scaled to this launch
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+    if os.path.exists(tpath) and args.graph == "linear":
+        tj = json.load(open(tpath))
+        if tj.get("kernel", "").startswith(kernel_name.split("<")[0]):
+            traffic = int(tj["hbm_bytes_per_column_update"] * st["column_updates"])
+            traffic_note = "scaled from profiles/r2_hbm_traffic.json (%s B per column update, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build %s)" % (tj["hbm_bytes_per_column_update"], tj.get("build", "?"))
+    if args.graph == "linear":
+        workload = ("E. coli-scale linear GFA (%d bp, %d-bp nodes, seed 42) + %d x %d bp simulated ONT-error reads (s,i,d=%s, seed 43), band=%d, 1 seed/read at pos 0"
+                    % (args.genome, args.node_len, args.reads, args.read_len, args.errors, args.bandwidth))
+    elif args.graph == "bubbles":
+        workload = ("yeast-like pangenome GFA (%d bp, SNP / indel / SV bubbles, nodes <= %d bp, seed 44) + %d x %d bp reads (s,i,d=%s), band=%d"
+                    % (args.genome, args.node_len, args.reads, args.read_len, args.errors, args.bandwidth))
+    else:
+        workload = ("chr22-like dense graph (%d bp seed 47, a SNP every ~45 bp and short indels seed 48, nodes <= %d bp) + %d x %d bp reads (s,i,d=%s), band=%d"
+                    % (args.genome, args.node_len, args.reads, args.read_len, args.errors, args.bandwidth))
+    e2e_s = t_prep_batch + k_ms * 1e-3 + t_collect
     out = {
         "metric": "aligned Gbp/sec (whole node), 10kb ONT reads vs chr-scale GFA",
         "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "E. coli-scale linear GFA (%d bp, %d-bp nodes, seed 42) + %d x %d bp simulated ONT-error reads (s=i=d=0.04, seed 43), band=%d, 1 seed/read at pos 0"
-                               % (args.genome, args.node_len, args.reads, args.read_len, args.bandwidth) if args.graph == "linear" else
-                               "pangenome-like bubble graph (%d bp, %d-bp nodes, seed 44) + %d x %d bp reads, band=%d" % (args.genome, args.node_len, args.reads, args.read_len, args.bandwidth),
-                   "reads_per_gpu": args.reads, "read_len": args.read_len, "bandwidth": args.bandwidth, "graph_bp_both_strands": int(graph.bp),
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": workload, "reads_per_gpu": args.reads, "read_len": args.read_len, "bandwidth": args.bandwidth, "graph_bp_both_strands": int(graph.bp),
                    "parallelism": "reads sharded, graph replicated, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": traffic, "kernel": "ga_extend_kernel<32,false>", "kernel_ms": round(k_ms, 3), "frac_of_measured_stream_copy": round(achieved / HBM_STREAM_GBS, 5),
+                     "traffic": traffic, "traffic_source": traffic_note, "kernel": kernel_name, "kernel_ms": round(dom_ms, 3), "frac_of_measured_stream_copy": round(achieved / HBM_STREAM_GBS, 5),
                      "column_updates_per_launch": int(st["column_updates"]), "bytes_per_column_update": BYTES_PER_COLUMN_UPDATE},
-        "detail": {"reads_failed": n_failed, "jobs": int(st["n_jobs"]), "jobs_retried_wide": int(st["jobs_retried"]), "slots": int(st["slots"]),
-                   "scratch_GB": round(st["scratch_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "prepare_s": round(t_prep, 1), "collect_s": round(t_collect, 2), "end_to_end_Gbp_s_incl_collect": round(aligned_bp / (k_ms * 1e-3 + t_collect) / 1e9, 3),
+        "detail": {"reads_failed": n_failed, "jobs": int(st["n_jobs"]), "jobs_left_to_the_wave_per_read_ladder": int(st["jobs_retried"]), "all_passes_ms": round(k_ms, 3),
+                   "waves": int(st["slots"]), "scratch_GB": round(st["scratch_bytes"] / 1e9, 2), "gen_s": round(t_gen, 1), "graph_upload_s": round(t_graph, 2),
+                   "prepare_s": round(t_prep_batch, 2), "collect_s": round(t_collect, 2),
+                   # reads in host memory -> results in host memory: job building + upload, all kernel passes, download + assembly
+                   "end_to_end_host_to_host_Gbp_s": round(aligned_bp / e2e_s / 1e9, 3),
                    "kernel_only_Gbp_s": round(aligned_bp / (k_ms * 1e-3) / 1e9, 4),
-                   "G_column_updates_per_s": round(st["column_updates"] / (k_ms * 1e-3) / 1e9, 3), "GCUPS": round(64 * st["column_updates"] / (k_ms * 1e-3) / 1e9, 1)},
+                   "G_column_updates_per_s": round(st["column_updates"] / (dom_ms * 1e-3) / 1e9, 3), "GCUPS": round(64 * st["column_updates"] / (dom_ms * 1e-3) / 1e9, 1)},
     }
 
-    # ---- CPU baseline: the oracle (a port of the reference algorithm), all host cores, bounded sample ----
+    # ---- CPU baseline: the oracle (a port of the reference algorithm), host cores, bounded sample ----
     if args.cpu_sample > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding as ob
@@ -192,17 +213,25 @@ def main():
         n = min(args.cpu_sample, len(reads))
         og = ob.OracleGraph(g.nodes, g.edges)
         b = og.bench(reads[:n], seeds[:n], args.bandwidth, 0, cores)
+        n1 = max(1, min(n, args.cpu_sample // 16))
+        b1 = og.bench(reads[:n1], seeds[:n1], args.bandwidth, 0, 1)
         out["cpu_baseline"] = {"value": round(b["aligned_bp"] / b["seconds"] / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
-                               "sample": "first %d reads of the same batch, %d threads popping reads from a shared queue (Aligner.cpp:285-298), %.1f s" % (n, cores, b["seconds"])}
-        # spot check: the GPU results for a few reads against the oracle
+                               "value_1_thread": round(b1["aligned_bp"] / b1["seconds"] / 1e9, 6),
+                               "sample": "first %d reads of the same batch, %d threads popping reads from a shared queue (Aligner.cpp:285-298), %.1f s; 1 thread: first %d reads, %.1f s"
+                                         % (n, cores, b["seconds"], n1, b1["seconds"])}
+        # spot check against the oracle: a regular sample plus every read that failed or was not finished by the first pass
         import parity_common as pc
-        k = min(args.check, n)
+        k = min(args.check, len(reads))
         if k:
-            some = graph.align(reads[:k], seeds[:k], args.bandwidth, 0)
-            for i in range(k):
-                assert some[i]["score"] == int(summary["score"][i])
-                pc.compare_read(dict(some[i], trace=np.zeros((0, 7), dtype=np.int64)), dict(og.align(reads[i], [seeds[i]], args.bandwidth), trace=np.zeros((0, 7), dtype=np.int64)), "bench read %d" % i)
-        out["detail"]["oracle_spot_check_reads"] = min(args.check, n)
+            special = [int(i) for i in np.nonzero((summary["failed"] != 0) | (summary["status"] != 0) | (summary["reserved"] != 0))[0][:k // 2]]
+            step = max(1, len(reads) // max(1, k - len(special)))
+            pick = sorted(set(list(range(0, len(reads), step))[:k - len(special)] + special))
+            some = graph.align([reads[i] for i in pick], [seeds[i] for i in pick], args.bandwidth, 0)
+            for d, i in zip(some, pick):
+                assert d["score"] == int(summary["score"][i]) or d["failed"]
+                pc.compare_read(dict(d, trace=np.zeros((0, 7), dtype=np.int64)), dict(og.align(reads[i], [seeds[i]], args.bandwidth), trace=np.zeros((0, 7), dtype=np.int64)), "bench read %d" % i)
+            out["detail"]["oracle_spot_check_reads"] = len(pick)
+            out["detail"]["oracle_spot_check_failed_or_later_pass_reads"] = len(special)
     if args.stamps:
         names = ["end_slice", "band+order", "trace_fast(in traceback)", "trace_general(in traceback)", "fill", "traceback", "trace_handover(in traceback)", "-"]
         tot = float(st["stamps"][0] + st["stamps"][1] + st["stamps"][4] + st["stamps"][5]) or 1.0

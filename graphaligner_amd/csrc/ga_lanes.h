@@ -300,20 +300,33 @@ template <int N> GAL_FN int project_band(const GaDevGraph& g, const LaneMem& m, 
 		cn++;
 		return totalCols >= kCutoff ? GA_UNSUPPORTED_BAND : GA_OK;
 	};
-	auto pushOut = [&](const uint32_t* rec, uint32_t node, int prio) -> int {
-		const uint32_t deg = rec[3] >> 16;
-		if (deg <= 4) { for (uint32_t e = 0; e < deg; e++) if (!heap_push<N>(l, heapSize, rec[4 + e], prio)) return GA_CAP_HEAP; }
+	// words 2 .. 7 of a node's graph record: length, degrees, first four out-neighbours
+	struct Rec6 { uint32_t w[6]; };
+	auto pushOut = [&](const Rec6& r, uint32_t node, int prio) -> int {
+		const uint32_t deg = r.w[1] >> 16;
+		if (deg <= 4) { for (uint32_t e = 0; e < deg; e++) if (!heap_push<N>(l, heapSize, r.w[2 + e], prio)) return GA_CAP_HEAP; }
 		else for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++) if (!heap_push<N>(l, heapSize, g.out_nbr[e], prio)) return GA_CAP_HEAP;
 		return GA_OK;
 	};
+	auto loadRec6 = [&](uint32_t node, Rec6& r) {
+		const uint32_t* rec = g_rec(g, node);
+#pragma unroll
+		for (int i = 0; i < 6; i++) r.w[i] = rec[2 + i];
+	};
+	// the previous band in map order; the record of the node after the one in hand is requested while that one is handled
+	Rec6 cur, nxt;
+	for (int i = 0; i < 6; i++) { cur.w[i] = 0; nxt.w[i] = 0; }
+	if (pn > 0) loadRec6(l.rd(LY::P_NODE + (int)l.rdb(LY::X_HASH, LY::HB_ORDER)), cur);
 	for (int k = 0; k < pn; k++)
 	{
 		const int s = (int)l.rdb(LY::X_HASH, LY::HB_ORDER + k);
+		if (k + 1 < pn) loadRec6(l.rd(LY::P_NODE + (int)l.rdb(LY::X_HASH, LY::HB_ORDER + k + 1)), nxt);
+		const Rec6 rec = cur;
+		cur = nxt;
 		const uint32_t pack = l.rd(LY::P_PACK + s);
 		if ((int)(pack >> 16) > bandwidth) continue;                              // node.minScore <= minScore + bandwidth (:1119)
 		const uint32_t node = l.rd(LY::P_NODE + s);
-		const uint32_t* rec = g_rec(g, node);
-		int rc = add(node, s, rec[2], pack & 0xffffu);
+		int rc = add(node, s, rec.w[0], pack & 0xffffu);
 		if (rc != GA_OK) return rc;
 		const int endScore = ew_end(l.rd(LY::P_END + s));
 		if (endScore > prevMin + expand) continue;
@@ -329,8 +342,9 @@ template <int N> GAL_FN int project_band(const GaDevGraph& g, const LaneMem& m, 
 		heap_pop<N>(l, heapSize);
 		if (find_in(l, LY::C_NODE, cn, node) >= 0) continue;                      // already at a distance <= prio
 		const int ps = find_in(l, LY::P_NODE, pn, node);
-		const uint32_t* rec = g_rec(g, node);
-		const uint32_t len = rec[2];
+		Rec6 rec;
+		loadRec6(node, rec);
+		const uint32_t len = rec.w[0];
 		int rc = add(node, ps, len, ps >= 0 ? (l.rd(LY::P_PACK + ps) & 0xffffu) : 0u);
 		if (rc != GA_OK) return rc;
 		rc = pushOut(rec, node, prio + (int)len);
@@ -349,12 +363,25 @@ template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, La
 	const Lds& l = m.lds;
 	const int cn = st.cn;
 	const int pn = st.pn;
+	// words 3 .. 11 of the node records (degrees, out- and in-neighbours), the next node's requested while this one is looked up
+	uint32_t cur[9], nxt[9];
+	auto loadRec9 = [&](int s, uint32_t (&r)[9]) {
+		const uint32_t* rec = g_rec(g, l.rd(LY::C_NODE + s));
+#pragma unroll
+		for (int i = 0; i < 9; i++) r[i] = rec[3 + i];
+	};
+	for (int i = 0; i < 9; i++) { cur[i] = 0; nxt[i] = 0; }
+	if (cn > 0) loadRec9(0, cur);
 	for (int s = 0; s < cn; s++)
 	{
-		const uint32_t* rec = g_rec(g, l.rd(LY::C_NODE + s));
+		if (s + 1 < cn) loadRec9(s + 1, nxt);
+		uint32_t rec[12];
+#pragma unroll
+		for (int i = 0; i < 9; i++) { rec[3 + i] = cur[i]; cur[i] = nxt[i]; }
 		const uint32_t outDeg = rec[3] >> 16, inDeg = rec[3] & 0xffffu;
 		if (outDeg > 4 || inDeg > 4) return GA_PUNT;
 		uint32_t slots = 0, inCur = 0, inPrv = 0;
+#pragma unroll
 		for (uint32_t e = 0; e < 4; e++)
 		{
 			int x = -1, ic = -1, ip = -1;
