@@ -1749,6 +1749,21 @@ std::vector<size_t> frozenIterationOrder(const std::vector<size_t>& nodes, size_
 	return out;
 }
 
+// component hooks for the tests that pin the oracle's helpers against the reference's own (tests/test_oracle_refparts.py)
+int interleavedRankForTest(uint64_t vp, uint64_t vn, int lo, int hi, int rank) { return interleavedRank(vp, vn, lo, hi, rank); }
+std::vector<size_t> workStackForTest(const std::vector<long long>& ops, size_t universe)
+{
+	WorkStack q(universe);
+	std::vector<size_t> popped;
+	for (long long op : ops)
+	{
+		if (op >= 0) q.push((size_t)op);
+		else if (q.size() > 0) { popped.push_back(q.top()); q.pop(); }
+	}
+	while (q.size() > 0) { popped.push_back(q.top()); q.pop(); }
+	return popped;
+}
+
 AlignResult alignOneWay(const Graph& g, const std::string& seqId, const std::string& sequence, int initialBandwidth, int rampBandwidth,
                         const std::vector<Seed>& seeds, std::vector<SliceRecord>* record)
 {

@@ -148,4 +148,8 @@ AlignResult alignOneWay(const Graph& g, const std::string& seqId, const std::str
 // iteration order of a frozen slice whose live form received `nodes` in this order (test hook)
 std::vector<size_t> frozenIterationOrder(const std::vector<size_t>& nodes, size_t graphNodes);
 
+// test hooks (see ga_oracle.cpp)
+int interleavedRankForTest(uint64_t vp, uint64_t vn, int lo, int hi, int rank);
+std::vector<size_t> workStackForTest(const std::vector<long long>& ops, size_t universe);
+
 }  // namespace gao

@@ -206,4 +206,13 @@ void gao_bench(void* g, const char* reads, const int64_t* offsets, const int64_t
 	for (int t = 0; t < threads; t++) { out[1] += bp[t]; out[2] += ok[t]; out[3] += cols[t]; out[4] += scores[t]; }
 }
 
+int gao_interleaved_rank(uint64_t vp, uint64_t vn, int lo, int hi, int rank) { return interleavedRankForTest(vp, vn, lo, hi, rank); }
+int gao_work_stack(const int64_t* ops, int nOps, int64_t universe, int64_t* popped)
+{
+	std::vector<long long> v(ops, ops + nOps);
+	std::vector<size_t> out = workStackForTest(v, (size_t)universe);
+	for (size_t i = 0; i < out.size(); i++) popped[i] = (int64_t)out[i];
+	return (int)out.size();
+}
+
 }  // extern "C"

@@ -19,6 +19,7 @@
 #include "WordSlice.h"
 #include "NodeSlice.h"
 #include "AlignmentCorrectnessEstimation.h"
+#include "UniqueQueue.h"
 
 typedef WordSlice<size_t, int, uint64_t> RefWord;
 
@@ -91,6 +92,42 @@ int ref_freeze_thaw(const int64_t* cols, int n, int mode, int64_t* out)
 		return 0;
 	}
 	catch (const ThreadReadAssertion::AssertionFailure&) { return 1; }
+}
+
+// WordConfiguration<uint64_t> helpers behind confirmedRowsInMerged (WordSlice.h:27-130)
+int ref_popcount(uint64_t x) { return WordConfiguration<uint64_t>::popcount(x); }
+uint64_t ref_chunk_popcounts(uint64_t x) { return WordConfiguration<uint64_t>::ChunkPopcounts(x); }
+uint64_t ref_morton_low(uint64_t a, uint64_t b) { return WordConfiguration<uint64_t>::MortonLow(a, b); }
+uint64_t ref_morton_high(uint64_t a, uint64_t b) { return WordConfiguration<uint64_t>::MortonHigh(a, b); }
+// the rank query of WordSlice.h:479-488: position of the rank-th set bit in the row-interleaved (VP, ~VN) words restricted to rows [lo, hi)
+int ref_interleaved_rank(uint64_t vp, uint64_t vn, int lo, int hi, int rank)
+{
+	try
+	{
+		uint64_t mask = hi < 64 ? ~(~0ull << hi) : ~0ull;
+		mask &= lo < 64 ? (~0ull << lo) : 0ull;
+		const uint64_t low = vp & mask, high = ~vn & mask;
+		return WordConfiguration<uint64_t>::BitPosition(WordConfiguration<uint64_t>::MortonLow(low, high), WordConfiguration<uint64_t>::MortonHigh(low, high), rank);
+	}
+	catch (const ThreadReadAssertion::AssertionFailure&) { return -1; }
+}
+
+// UniqueQueue<size_t> (UniqueQueue.h:6-69) driven by a list of operations: op >= 0 insert(op), op == -1 pop.  Returns the popped items.
+int ref_unique_queue(const int64_t* ops, int nOps, int64_t universe, int64_t* popped)
+{
+	try
+	{
+		UniqueQueue<size_t> q((size_t)universe);
+		int k = 0;
+		for (int i = 0; i < nOps; i++)
+		{
+			if (ops[i] >= 0) q.insert((size_t)ops[i]);
+			else if (q.size() > 0) { popped[k++] = (int64_t)q.top(); q.pop(); }
+		}
+		while (q.size() > 0) { popped[k++] = (int64_t)q.top(); q.pop(); }
+		return k;
+	}
+	catch (const ThreadReadAssertion::AssertionFailure&) { return -1; }
 }
 
 }  // extern "C"

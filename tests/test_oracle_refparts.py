@@ -144,3 +144,49 @@ def test_freeze_thaw_matches_reference():
                     assert out[i, 3] == cols[i, 3]
                     assert out[i, 2] == 0
                 assert out[i, 4] == 64 and out[i, 5] == 0 and out[i, 6] == 0 and out[i, 7] == 1
+
+
+def test_rank_queries_and_word_helpers_match_reference():
+    """WordConfiguration::{popcount, ChunkPopcounts, MortonLow/High, BitPosition} (WordSlice.h:27-130) as confirmedRowsInMerged uses
+    them (:479-488): the oracle answers the same rank query with a plain loop"""
+    rng = np.random.default_rng(11)
+    L = ob.lib()
+    L.gao_interleaved_rank.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    ref.ref_interleaved_rank.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    ref.ref_popcount.argtypes = [C.c_uint64]
+    ref.ref_chunk_popcounts.argtypes = [C.c_uint64]
+    ref.ref_chunk_popcounts.restype = C.c_uint64
+    for f in (ref.ref_morton_low, ref.ref_morton_high):
+        f.argtypes = [C.c_uint64, C.c_uint64]
+        f.restype = C.c_uint64
+    for trial in range(3000):
+        vp = int(rng.integers(0, 1 << 63, dtype=np.uint64)) | (int(rng.integers(0, 2)) << 63)
+        vn = int(rng.integers(0, 1 << 63, dtype=np.uint64)) & ~vp
+        assert ref.ref_popcount(vp) == bin(vp).count("1")
+        cp = ref.ref_chunk_popcounts(vp)
+        assert [(cp >> (8 * k)) & 0xff for k in range(8)] == [bin((vp >> (8 * k)) & 0xff).count("1") for k in range(8)]
+        a, b = vp & 0xffffffff, vn & 0xffffffff
+        want = sum(((a >> i) & 1) << (2 * i) | ((b >> i) & 1) << (2 * i + 1) for i in range(32))
+        assert ref.ref_morton_low(vp, vn) == want
+        assert ref.ref_morton_high(vp, vn) == sum((((vp >> 32) >> i) & 1) << (2 * i) | (((vn >> 32) >> i) & 1) << (2 * i + 1) for i in range(32))
+        lo = int(rng.integers(0, 63))
+        hi = int(rng.integers(lo + 1, 65))
+        units = bin(vp & ((1 << hi) - 1) & ~((1 << lo) - 1)).count("1") + bin(~vn & ((1 << hi) - 1) & ~((1 << lo) - 1) & ((1 << 64) - 1)).count("1")
+        for rank in (0, 1, int(rng.integers(0, 130)), units - 1 if units else 0, units):
+            assert L.gao_interleaved_rank(vp, vn, lo, hi, rank) == ref.ref_interleaved_rank(vp, vn, lo, hi, rank), (hex(vp), hex(vn), lo, hi, rank)
+
+
+def test_work_stack_matches_reference_unique_queue():
+    """the LIFO work list with membership flags that drives the per-component relaxation (UniqueQueue.h:6-69, GraphAligner.h:2364-2397)"""
+    rng = np.random.default_rng(12)
+    L = ob.lib()
+    L.gao_work_stack.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+    ref.ref_unique_queue.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+    for trial in range(300):
+        universe = int(rng.integers(1, 50))
+        ops = np.where(rng.random(200) < 0.35, -1, rng.integers(0, universe, size=200)).astype(np.int64)
+        o1 = np.zeros(300, dtype=np.int64)
+        o2 = np.zeros(300, dtype=np.int64)
+        n1 = L.gao_work_stack(ob._p(ops), len(ops), universe, ob._p(o1))
+        n2 = ref.ref_unique_queue(ob._p(ops), len(ops), universe, ob._p(o2))
+        assert n1 == n2 and (o1[:n1] == o2[:n2]).all()
