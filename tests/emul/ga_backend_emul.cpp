@@ -249,3 +249,52 @@ extern "C" int ga_emul_heap(const uint32_t* nodes, const int32_t* prios, int nOp
 	while (size > 0) { popped[k++] = ws->heap_node[0]; gak::heap_pop(*ws, size); }
 	return k;
 }
+
+// ---- component hooks for the lanes = reads program (graphaligner_amd/csrc/ga_lanes.h) ---------------------------------------
+// column = {vp, vn, before}
+extern "C" void ga_emul_lanes_merge(const uint64_t* a, const uint64_t* b, uint64_t* out)
+{
+	gal::Col x{a[0], a[1], (int)(int64_t)a[2]}, y{b[0], b[1], (int)(int64_t)b[2]};
+	gal::column_merge(x, y);
+	out[0] = x.vp; out[1] = x.vn; out[2] = (uint64_t)(int64_t)x.before;
+}
+// the vertical re-entry: cell-wise minimum with the run coming down from a cell d below the column's row j-1 score
+extern "C" void ga_emul_lanes_reenter(const uint64_t* a, int d, uint64_t* out)
+{
+	gal::Col x{a[0], a[1], (int)(int64_t)a[2]};
+	gal::column_reenter(x, d);
+	out[0] = x.vp; out[1] = x.vn; out[2] = (uint64_t)(int64_t)x.before;
+}
+// one column step (Eq word, "no diagonal into row j", new row j-1 score)
+extern "C" void ga_emul_lanes_step(const uint64_t* a, uint64_t eq, int noDiag, int calc, uint64_t* out)
+{
+	gal::Col x{a[0], a[1], (int)(int64_t)a[2]};
+	gal::column_step(x, eq, noDiag != 0, calc);
+	out[0] = x.vp; out[1] = x.vn; out[2] = (uint64_t)(int64_t)x.before;
+}
+// map iteration order and heap pop order of the per-lane tables (one lane, N = 56)
+extern "C" int ga_emul_lanes_hash_order(const uint32_t* keys, int n, int32_t* out)
+{
+	typedef gal::Lay<56> LY;
+	if (n > 56) return -1;
+	std::vector<uint32_t> lds((size_t)LY::WORDS);
+	gal::Lds l{lds.data(), 1};
+	for (int i = 0; i < n; i++) l.wr(LY::P_NODE + i, keys[i]);
+	gal::hash_order<56>(l, n);
+	for (int i = 0; i < n; i++) out[i] = (int32_t)l.rdb(LY::X_HASH, LY::HB_ORDER + i);
+	return n;
+}
+extern "C" int ga_emul_lanes_heap(const uint32_t* nodes, const int32_t* prios, int nOps, uint32_t* popped)
+{
+	typedef gal::Lay<56> LY;
+	std::vector<uint32_t> lds((size_t)LY::WORDS);
+	gal::Lds l{lds.data(), 1};
+	int size = 0, k = 0;
+	for (int i = 0; i < nOps; i++)
+	{
+		if (prios[i] >= 0) { if (!gal::heap_push<56>(l, size, nodes[i], prios[i])) return -1; }
+		else if (size > 0) { popped[k++] = l.rd(LY::X_HEAPN); gal::heap_pop<56>(l, size); }
+	}
+	while (size > 0) { popped[k++] = l.rd(LY::X_HEAPN); gal::heap_pop<56>(l, size); }
+	return k;
+}
