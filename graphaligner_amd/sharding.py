@@ -31,3 +31,70 @@ def align_sharded(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None):
         for i, r in zip(idx, res):
             out[i] = r
     return out
+
+
+# ---- work queue (the reference's scheduler is a mutex-guarded pop, Aligner.cpp:107-117, 285-298) ----------------
+def make_chunks(lengths, chunk_reads):
+    """reads sorted longest first, cut into chunks of `chunk_reads` (a chunk should fill a GPU: one lanes = reads wave carries 64
+    reads and an MI355X holds 1024 such waves, so the default is 65536)"""
+    order = np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable")
+    return [[int(i) for i in order[k:k + chunk_reads]] for k in range(0, len(order), chunk_reads)]
+
+
+class _Counter:
+    """the shared "next chunk" counter: the process group's store (a TCP store on 127.0.0.1 for a single node) when there are
+    several ranks, a local integer otherwise"""
+
+    def __init__(self, dist, key):
+        self.key, self.local, self.store = key, 0, None
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d as c10d
+            self.store = c10d._get_default_store()
+
+    def next(self):
+        if self.store is None:
+            self.local += 1
+            return self.local - 1
+        return int(self.store.add(self.key, 1)) - 1
+
+
+def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chunk_reads=65536, tag="ga_queue"):
+    """every rank calls this with the SAME reads/seeds and its own `graph` (already uploaded to its GPU).  Chunks of reads are pulled
+    from a shared counter, so a rank that finishes early takes more; on each rank three stages overlap on separate host threads and
+    HIP streams: job building + upload of chunk k+1, the kernels of chunk k, download + assembly of chunk k-1.  Rank 0 gets the full
+    result list in input order, other ranks get None.  No collective on the data path."""
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = make_chunks([len(r) for r in reads], chunk_reads)
+    counter = _Counter(dist, tag)
+    multi = counter.store is not None
+
+    def take():
+        k = counter.next()
+        return k if k < len(chunks) else None
+
+    def prep(k):
+        idx = chunks[k]
+        return k, graph.prepare([reads[i] for i in idx], [seeds[i] for i in idx], bandwidth, ramp, flags)
+
+    done = []                         # (chunk number, future of its results)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        k = take()
+        nxt = pool.submit(prep, k) if k is not None else None
+        while nxt is not None:
+            k, batch = nxt.result()
+            k2 = take()
+            nxt = pool.submit(prep, k2) if k2 is not None else None      # built and uploaded while chunk k runs
+            batch.run()
+            done.append((k, pool.submit(batch.collect)))                 # assembled while the next chunk runs
+        mine = [(k, f.result()) for k, f in done]
+    if multi:
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        if dist.get_rank() != 0:
+            return None
+        mine = [kr for part in gathered for kr in part]
+    out = [None] * len(reads)
+    for k, res in mine:
+        for i, r in zip(chunks[k], res):
+            out[i] = r
+    return out

@@ -32,10 +32,14 @@ def _worker(rank, world, port, lib, q):
     reads, seeds = synth.simulate_reads(g, 10, 900, seed=32)
     reads = [r[: 500 + 40 * i] for i, r in enumerate(reads)]       # ragged lengths
     graph = binding.Graph(g.nodes, g.edges, lib_path=lib)
+    reads[3] = reads[3][:120]                                       # fails (fewer than four slices): the failure must come back in place
     res = sharding.align_sharded(graph, reads, seeds, 35, dist=dist)
+    # the work queue: chunks of 3 reads pulled from the shared counter (ragged: 10 reads = 3 + 3 + 3 + 1), whichever rank is free
+    queued = sharding.align_queued(graph, reads, seeds, 35, dist=dist, chunk_reads=3)
     if rank == 0:
         single = graph.align(reads, seeds, 35)
-        ok = all(a["score"] == b["score"] and a["mappings"] == b["mappings"] and a["status"] == b["status"] for a, b in zip(res, single))
+        same = lambda x, y: all(a["score"] == b["score"] and a["mappings"] == b["mappings"] and a["status"] == b["status"] and a["failed"] == b["failed"] for a, b in zip(x, y))
+        ok = same(res, single) and same(queued, single) and single[3]["failed"] and sum(1 for r in single if r["failed"]) == 1
         import oracle_binding as ob
         og = ob.OracleGraph(g.nodes, g.edges)
         ok2 = all(r["score"] == og.align(x, [s], 35)["score"] for r, x, s in zip(res, reads, seeds) if not r["failed"])
