@@ -164,7 +164,7 @@ def main():
     k_ms = float(np.mean(kernel_ms))                   # all kernel passes of a step
     main_ms = float(np.mean(main_kernel_ms))           # the dominant kernel alone: the first pass over all jobs
     variant = int(st["main_variant"])
-    kernel_name = ("ga_lanes_kernel<%d,%d>" % (variant // 1000, 32 if variant % 10 else 64)) if variant else "ga_extend_kernel<64,false>"
+    kernel_name = ("ga_lanes_kernel<%d,%d>" % (variant // 1000, 32 if variant % 10 else 64)) if variant > 0 else "ga_extend_kernel<%d,false>" % (-variant if variant else 64)
     dom_ms = main_ms if variant else k_ms
     achieved = BYTES_PER_COLUMN_UPDATE * st["column_updates"] / (dom_ms * 1e-3) / 1e9
     # HBM traffic per launch: PMC counters cannot be read from inside this process, so the per-column-update figure measured with

@@ -6,6 +6,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "ga_types.h"
@@ -73,7 +74,10 @@ public:
 GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& g, const GaHmmTables& hmm, int device, int* status);
 // eq: per job and 64-row slice five 64-bit words (job j, slice s at (jobs[j].rows_off / 64 + s) * 5): the match words of the slice's rows
 // against A, C, G, T and a meta word (bits 0-2 exact-compare code of the slice's last row, bit 3 = a row with an invalid character)
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
+// rows: the row codes (one byte per padded read base) are only needed by the wave-per-read ladder kernels, so they are built and uploaded
+// on demand: the provider returns them (building them at its first call)
+typedef std::function<const std::vector<uint8_t>&()> GaRowsProvider;
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status);
 
 // the match words of ga_backend_create_batch from the row codes

@@ -179,6 +179,7 @@ struct DevBatch : GaBackendBatch
 	std::vector<uint8_t> passOf;       // which pass of the last run finished each job (0 = the first)
 	int passNo = 0;
 	GaRunStats st;
+	GaRowsProvider rowsProvider;       // row codes for the wave-per-read kernels, uploaded when the first of them is about to run
 	uint8_t* privateScratch = nullptr; // only when the graph's pool is taken by another batch
 	size_t privateBytes = 0;
 
@@ -200,7 +201,18 @@ struct DevBatch : GaBackendBatch
 		return 0;
 	}
 
-	int init(const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobsIn)
+	int ensureRows()
+	{
+		if (L.rows) return 0;
+		const std::vector<uint8_t>& rows = rowsProvider();
+		uint8_t* dRows;
+		if (alloc(&dRows, rows.size())) return GA_E_DEVICE;
+		HIP_OK(hipMemcpyAsync(dRows, rows.data(), rows.size(), hipMemcpyHostToDevice, stream));
+		L.rows = dRows;
+		return 0;
+	}
+
+	int init(const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobsIn)
 	{
 		HIP_OK(hipSetDevice(g->device));
 		HIP_OK(hipStreamCreate(&stream));
@@ -214,14 +226,12 @@ struct DevBatch : GaBackendBatch
 		L.initial_bw = cfg.initial_bw;
 		L.ramp_bw = cfg.ramp_bw;
 		L.max_slices = std::max<uint32_t>(cfg.max_slices, 1);
-		uint8_t* dRows; GaJob* dJobs; uint64_t* eqDev;
-		if (alloc(&dRows, rows.size())) return GA_E_DEVICE;
+		GaJob* dJobs; uint64_t* eqDev;
 		if (alloc(&eqDev, eq.size())) return GA_E_DEVICE;
 		if (alloc(&dJobs, jobs.size())) return GA_E_DEVICE;
-		HIP_OK(hipMemcpyAsync(dRows, rows.data(), rows.size(), hipMemcpyHostToDevice, stream));
 		HIP_OK(hipMemcpyAsync(eqDev, eq.data(), eq.size() * 8, hipMemcpyHostToDevice, stream));
 		HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GaJob), hipMemcpyHostToDevice, stream));
-		L.rows = dRows;
+		L.rows = nullptr;
 		L.jobs = dJobs;
 		dEq = eqDev;
 		// the device queues hand jobs out longest first: the short ones fill the tail of a launch, and the 64 jobs a lanes = reads
@@ -336,6 +346,7 @@ struct DevBatch : GaBackendBatch
 		std::vector<uint32_t> again;
 		for (uint32_t i : orderHost) if ((takeCapacity && isCapacity(outs[i].status)) || (takeGeneral && needsGeneral(outs[i].status))) again.push_back(i);
 		if (again.empty()) return 0;
+		if (ensureRows()) return GA_E_DEVICE;
 		for (uint32_t i : again) passOf[i] = (uint8_t)passNo;
 		passNo++;
 		st.jobs_retried += again.size();
@@ -354,6 +365,7 @@ struct DevBatch : GaBackendBatch
 		uint8_t* scratch = takeScratch((size_t)rslots * lay.bytes, fromPool);
 		if (!scratch) return 0;                            // the affected jobs keep their capacity status
 		Rl.scratch = scratch;
+		if (passNo == 1) { st.slots = rslots; st.waves_per_cu = wavesPerCuRetry; st.scratch_bytes = (uint64_t)rslots * lay.bytes; }
 		Rl.job_list = dList;
 		Rl.n_jobs = (uint32_t)again.size();
 		int rc = uploadList(again);
@@ -383,12 +395,15 @@ struct DevBatch : GaBackendBatch
 		HIP_OK(hipMemsetAsync(L.trace_top, 0, 16, stream));
 		// ---- first the lanes = reads kernel: one job per lane.  Its LDS tables hold 16, 32 or 64 band nodes per lane (4, 2, 1
 		// waves per CU); the starting size follows the graph's mean node length, and jobs a size cannot hold move to the next ----
-		const bool useLanes = !(getenv("GA_LANES") && atoi(getenv("GA_LANES")) == 0);
+		// It is the first pass where its lockstep pays: the lanes of a wave take their k-th band node together, so on graphs of long,
+		// equally long nodes (mean node length >= 40 bp: linear and sparsely branching graphs) every lane is busy; on graphs chopped
+		// into short uneven nodes the wave-per-read kernel is still the faster one and goes first.  GA_LANES=1 / 0 forces the choice.
+		const double meanNode = g->g.n_nodes > 2 ? (double)g->totalBp / (double)(g->g.n_nodes - 2) : 64.0;
+		const bool useLanes = getenv("GA_LANES") ? atoi(getenv("GA_LANES")) != 0 : meanNode >= 40;
 		const int half = getenv("GA_LANES_PER_WAVE") && atoi(getenv("GA_LANES_PER_WAVE")) == 32;
 		int rc = 0;
 		if (useLanes)
 		{
-			const double meanNode = g->g.n_nodes > 2 ? (double)g->totalBp / (double)(g->g.n_nodes - 2) : 64.0;
 			int startN = meanNode >= 40 ? 0 : meanNode >= 14 ? 1 : 2;
 			if (getenv("GA_LANES_N")) startN = atoi(getenv("GA_LANES_N"));
 			std::vector<uint32_t> list = orderHost;
@@ -411,6 +426,15 @@ struct DevBatch : GaBackendBatch
 		// ---- what is left climbs the wave-per-read ladder: 64 band nodes in LDS; then the general variants, which also carry the
 		// paths for bands with cycles and for ramp redos; last 256 band nodes with large buffers ----
 		st.jobs_retried = 0;
+		if (!useLanes)
+		{
+			// the lean wave-per-read variant over everything (32 band nodes in LDS, 24 waves per CU)
+			rc = retryPass<32, false>(4096, 3 * 64 + 5 * 800, 2, 24, true, false);
+			if (rc) return rc;
+			st.main_ms = st.kernel_ms;
+			st.main_variant = -32;                         // (negative: the wave-per-read kernel with that many band nodes in LDS)
+			st.jobs_retried = 0;
+		}
 		rc = retryPass<64, false>(8192, 3 * 64 + 5 * 2048, 3, 12, true, false);
 		if (rc) return rc;
 		rc = retryPass<64, true>(8192, 3 * 64 + 5 * 4096, 4, 8, false, true);      // only what needs the extra paths: capacity misses go straight on
@@ -468,13 +492,14 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, GaRowsProvider rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status)
 {
 	DevBatch* b = new DevBatch();
 	b->g = static_cast<DevGraph*>(graph);
 	b->cfg = cfg;
-	int s = b->init(rows, eq, jobs);
+	b->rowsProvider = rows;
+	int s = b->init(eq, jobs);
 	if (s) { delete b; *status = s; return nullptr; }
 	*status = 0;
 	return b;

@@ -231,16 +231,50 @@ struct ga_batch
 	std::vector<std::string> names, seqs;
 	std::vector<ReadPlan> reads;
 	std::vector<SeedPlan> seeds;
-	std::vector<uint8_t> rows;
+	struct RowFill { size_t read; uint64_t off, n, padded, pos; bool backward; };
+	std::vector<RowFill> fills;         // where every job's rows come from
+	std::vector<uint8_t> rows;          // row codes, built when a kernel that wants them is about to run (see buildRows)
 	std::vector<uint64_t> eq;
 	std::vector<GaJob> jobs;
 	GaRunConfig cfg;
 	uint32_t flags = 0;
 	GaBackendBatch* dev = nullptr;
 	bool ran = false;
-	uint64_t columnUpdates = 0, slicesRun = 0;
+	uint64_t columnUpdates = 0, slicesRun = 0, rowsTotal = 0;
 	~ga_batch() { delete dev; }
 };
+
+// run `fn(fill, read sequence)` for every job's rows on the host threads
+template <typename F> static void forEachFill(ga_batch* b, F fn)
+{
+	const auto& fills = b->fills;
+	size_t nThreads = std::thread::hardware_concurrency();
+	if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
+	nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), fills.size() / 64 + 1));
+	std::vector<std::thread> pool;
+	const size_t per = (fills.size() + nThreads - 1) / nThreads;
+	for (size_t t = 0; t < nThreads; t++)
+	{
+		const size_t lo = std::min(fills.size(), t * per), hi = std::min(fills.size(), lo + per);
+		if (lo < hi) pool.emplace_back([&, lo, hi]() { for (size_t k = lo; k < hi; k++) fn(fills[k], b->seqs[fills[k].read]); });
+	}
+	for (auto& th : pool) th.join();
+}
+
+// the row codes (one byte per padded read base: match set, exact-compare code, validity): only the wave-per-read kernels read them
+static void buildRows(ga_batch* b)
+{
+	if (!b->rows.empty()) return;
+	const CharTables& T = tables();
+	b->rows.assign(b->rowsTotal + 64, 0);       // (+ slack so a 64-byte row load never leaves the buffer)
+	forEachFill(b, [&](const ga_batch::RowFill& f, const std::string& seq) {
+		const uint8_t padCode = T.rowCode[(uint8_t)'N'];
+		uint8_t* dst = b->rows.data() + f.off;
+		if (f.backward) for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[T.complement[(uint8_t)seq[f.n - 1 - r]]];
+		else for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[(uint8_t)seq[f.pos + r]];
+		for (uint64_t r = f.n; r < f.padded; r++) dst[r] = padCode;
+	});
+}
 
 namespace {
 
@@ -536,8 +570,8 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	b->seqs.resize(nReads);
 	auto pad64 = [](uint64_t n) { return (n + W - 1) / W * W; };
 	// the jobs are planned first (sizes and offsets only); their row codes, one byte per read base, are written afterwards by all host threads
-	struct RowFill { size_t read; uint64_t off, n, padded, pos; bool backward; };
-	std::vector<RowFill> fills;
+	typedef ga_batch::RowFill RowFill;
+	std::vector<RowFill>& fills = b->fills;
 	uint64_t rowsTotal = 0;
 	for (size_t i = 0; i < nReads; i++)
 	{
@@ -598,36 +632,24 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		b->cfg.max_rows = std::max(b->cfg.max_rows, j.n_rows);
 		b->cfg.max_slices = std::max(b->cfg.max_slices, j.n_rows / W);
 	}
-	b->rows.assign(rowsTotal + 64, 0);          // (+ slack so a 64-byte row load never leaves the buffer)
+	b->rowsTotal = rowsTotal;
 	b->eq.assign((rowsTotal / W + 1) * 5, 0);   // match words per slice for the lanes = reads kernel
-	{
-		size_t nThreads = std::thread::hardware_concurrency();
-		if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
-		nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), fills.size() / 64 + 1));
-		auto fill = [&](size_t lo, size_t hi) {
-			const uint8_t padCode = T.rowCode[(uint8_t)'N'];
-			for (size_t k = lo; k < hi; k++)
-			{
-				const RowFill& f = fills[k];
-				const std::string& seq = b->seqs[f.read];
-				uint8_t* dst = b->rows.data() + f.off;
-				if (f.backward) for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[T.complement[(uint8_t)seq[f.n - 1 - r]]];
-				else for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[(uint8_t)seq[f.pos + r]];
-				for (uint64_t r = f.n; r < f.padded; r++) dst[r] = padCode;
-				ga_build_eq_words(dst, f.padded, b->eq.data() + f.off / W * 5);
-			}
-		};
-		std::vector<std::thread> pool;
-		const size_t per = (fills.size() + nThreads - 1) / nThreads;
-		for (size_t t = 0; t < nThreads; t++)
+	forEachFill(b, [&](const RowFill& f, const std::string& seq) {
+		// 64 row codes at a time, straight into the slice's match words
+		const uint8_t padCode = T.rowCode[(uint8_t)'N'];
+		uint8_t buf[W];
+		for (uint64_t r0 = 0; r0 < f.padded; r0 += W)
 		{
-			const size_t lo = std::min(fills.size(), t * per), hi = std::min(fills.size(), lo + per);
-			if (lo < hi) pool.emplace_back(fill, lo, hi);
+			for (uint64_t k = 0; k < (uint64_t)W; k++)
+			{
+				const uint64_t r = r0 + k;
+				buf[k] = r >= f.n ? padCode : f.backward ? T.rowCode[T.complement[(uint8_t)seq[f.n - 1 - r]]] : T.rowCode[(uint8_t)seq[f.pos + r]];
+			}
+			ga_build_eq_words(buf, W, b->eq.data() + (f.off + r0) / W * 5);
 		}
-		for (auto& th : pool) th.join();
-	}
+	});
 	int status = GA_S_OK;
-	b->dev = ga_backend_create_batch(g->device, b->rows, b->eq, b->jobs, b->cfg, &status);
+	b->dev = ga_backend_create_batch(g->device, [b]() -> const std::vector<uint8_t>& { buildRows(b); return b->rows; }, b->eq, b->jobs, b->cfg, &status);
 	if (!b->dev) { delete b; return status ? status : GA_E_DEVICE; }
 	*out = b;
 	return GA_S_OK;

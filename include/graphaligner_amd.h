@@ -152,7 +152,8 @@ typedef struct ga_batch_stats {
 	uint64_t scratch_bytes;
 	uint64_t stamps[8];          /* diagnostic builds (GA_STAMPS) only: shader cycles per phase, summed over jobs */
 	double main_kernel_ms;       /* HIP-event time of the first pass alone (the lanes = reads kernel over all jobs) */
-	int32_t main_variant;        /* its variant: band nodes per lane * 1000 + record block * 10 + (1 when 32 lanes per wave); 0 = none */
+	int32_t main_variant;        /* > 0: lanes = reads kernel, band nodes per lane * 1000 + record block * 10 + (1 when 32 lanes per wave);
+	                                < 0: wave-per-read kernel with that many band nodes in LDS */
 	int32_t reserved;
 } ga_batch_stats_t;
 int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out);

@@ -31,6 +31,7 @@ struct EmulGraph : GaBackendGraph
 struct EmulBatch : GaBackendBatch
 {
 	EmulGraph* g;
+	GaRowsProvider rowsProvider;
 	std::vector<uint8_t> rows;
 	std::vector<uint64_t> eq;
 	std::vector<GaJob> jobs;
@@ -141,6 +142,7 @@ struct EmulBatch : GaBackendBatch
 			}
 		}
 		lanesDone = 0;
+		if (rows.empty()) rows = rowsProvider();         // the wave-per-read kernels below read the row codes
 		if (getenv("GA_EMUL_DEBUG") && lanesFirst) { int hist[100] = {0}; for (auto& o : outs) hist[o.status < 100 ? o.status : 99]++; fprintf(stderr, "emul: lanes statuses:"); for (int i = 0; i < 100; i++) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]); fprintf(stderr, "\n"); }
 		for (uint32_t j = 0; j < jobs.size(); j++)
 		{
@@ -190,11 +192,11 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, const std::vector<uint8_t>& rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
 {
 	EmulBatch* b = new EmulBatch();
 	b->g = static_cast<EmulGraph*>(g);
-	b->rows = rows;
+	b->rowsProvider = rows;
 	b->eq = eq;
 	b->jobs = jobs;
 	b->cfg = cfg;

@@ -30,6 +30,15 @@ def _need_gpu():
     assert torch.cuda.is_available(), "these tests need a real MI355X"
 
 
+@pytest.fixture(autouse=True, params=["lanes-first", "by-graph-shape"])
+def _first_pass(request, monkeypatch):
+    """both first-pass kernels on every configuration: the lanes = reads kernel forced, and the library's own choice by graph shape"""
+    if request.param == "lanes-first":
+        monkeypatch.setenv("GA_LANES", "1")
+    else:
+        monkeypatch.delenv("GA_LANES", raising=False)
+
+
 def _properties(res, reads, seeds, min_ok):
     """size-independent checks on every read: rows monotone, path length bounded by the read, and -- for reads seeded at their
     first base, where the reference's TraceItem types are meaningful (the items of a backward part are typed after the trace was

@@ -15,6 +15,16 @@ def _need_gpu():
     assert torch.cuda.is_available(), "these tests need a real MI355X"
 
 
+@pytest.fixture(autouse=True, params=["lanes-first", "by-graph-shape"])
+def _first_pass(request, monkeypatch):
+    """every case runs twice: with the lanes = reads kernel forced as the first pass (whatever the graph looks like; jobs it declines
+    climb the wave-per-read ladder), and with the library's own choice by graph shape (short-node graphs start in the wave-per-read kernel)"""
+    if request.param == "lanes-first":
+        monkeypatch.setenv("GA_LANES", "1")
+    else:
+        monkeypatch.delenv("GA_LANES", raising=False)
+
+
 def test_wave_primitives_on_hardware():
     cases.case_wave_primitives_on_hardware()
 

@@ -1,0 +1,17 @@
+# round-2 evidence: kernel trace stats of the default bench, counters of the lanes = reads kernel (separate --pmc passes), and the
+# bench lines of the three graph shapes.  usage on the GPU box: bash tools/profile_round2.sh
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+O=gpurun_out/prof2
+rm -rf $O && mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --check 0 > $O/stats_bench.json 2> $O/stats.err
+echo "stats done"
+bash tools/pmc_lanes.sh > $O/pmc.log 2>&1
+cp gpurun_out/pmc_lanes/summary.json $O/pmc_summary.json
+echo "pmc done"
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+echo "bench done"
+python3 bench.py --graph bubbles --genome 12100000 --reads 20000 --cpu-sample 0 --check 32 --steps 2 --warmup 1 > $O/bench_bubbles.json 2> $O/bench_bubbles.err
+GA_DEBUG_PASSES=1 python3 bench.py --graph dense --node-len 32 --genome 3000000 --reads 16000 --read-len 15000 --errors 0.02,0.08,0.05 --cpu-sample 0 --check 32 --steps 2 --warmup 1 > $O/bench_dense.json 2> $O/bench_dense.err
+find $O -name "*kernel_stats.csv" | head
