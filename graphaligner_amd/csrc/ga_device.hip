@@ -413,7 +413,7 @@ struct DevBatch : GaBackendBatch
 				// later sizes are only worth a launch of their own for enough jobs to fill waves; stragglers take the wave-per-read ladder
 				if (!first && list.size() < 512) break;
 				// (10 / 24 / 56 band nodes per lane = 4 / 2 / 1 waves per CU next to the 12.8 KB block image)
-				if (n == 0) rc = half ? lanesPass<10, 32>(list, 400, first) : lanesPass<10, 64>(list, 400, first);
+				if (n == 0) rc = half ? lanesPass<10, 32>(list, getenv("GA_ROWS_PER_SLICE") ? atoi(getenv("GA_ROWS_PER_SLICE")) : 400, first) : lanesPass<10, 64>(list, 400, first);
 				else if (n == 1) rc = lanesPass<24, 64>(list, 1024, first);
 				else rc = lanesPass<56, 64>(list, 2560, first);
 				first = false;
