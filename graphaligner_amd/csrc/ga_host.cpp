@@ -694,7 +694,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	const auto t1 = std::chrono::steady_clock::now();
 	b->columnUpdates = 0;
 	b->slicesRun = 0;
-	for (const GaJobOut& o : outs) { b->columnUpdates += o.n_columns; b->slicesRun += o.n_run; }
+	for (const GaJobOut& o : outs) b->slicesRun += o.n_run;         // (column updates are summed per read below: seeds the reference would skip do not count)
 	ResultsOwner* R = new ResultsOwner();
 	const int32_t kMax = std::numeric_limits<int32_t>::max();
 
@@ -854,6 +854,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		}
 		for (auto& th : pool) th.join();
 	}
+	for (const ResultsOwner& part : parts) for (const ga_read_result_t& rr : part.reads) b->columnUpdates += rr.column_updates;
 	const auto t2 = std::chrono::steady_clock::now();
 	// stitch the per-thread arrays: sizes first, then every part copies itself into place (rebased offsets) on its own thread
 	{

@@ -19,27 +19,35 @@ namespace {
 
 bool gunzipAll(const uint8_t* data, size_t len, std::vector<uint8_t>& out)
 {
-	// concatenated gzip members are allowed (one per stream::write call)
+	// concatenated gzip members are allowed (one per stream::write call); zlib's counters are 32-bit, so input is fed in pieces
 	size_t at = 0;
 	while (at < len)
 	{
 		z_stream z;
 		memset(&z, 0, sizeof(z));
 		if (inflateInit2(&z, 16 + MAX_WBITS) != Z_OK) return false;
+		size_t fed = at;                          // bytes of `data` handed to zlib so far
 		z.next_in = const_cast<Bytef*>(data + at);
-		z.avail_in = (uInt)std::min<size_t>(len - at, 1u << 30);
+		z.avail_in = 0;
 		int rc = Z_OK;
 		uint8_t buf[1 << 16];
 		while (rc != Z_STREAM_END)
 		{
+			if (z.avail_in == 0 && fed < len)
+			{
+				const size_t piece = std::min<size_t>(len - fed, 1u << 30);
+				z.next_in = const_cast<Bytef*>(data + fed);
+				z.avail_in = (uInt)piece;
+				fed += piece;
+			}
 			z.next_out = buf;
 			z.avail_out = sizeof(buf);
 			rc = inflate(&z, Z_NO_FLUSH);
 			if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&z); return false; }
 			out.insert(out.end(), buf, buf + (sizeof(buf) - z.avail_out));
-			if (rc == Z_OK && z.avail_in == 0 && z.avail_out != 0) { inflateEnd(&z); return false; }   // truncated
+			if (rc == Z_OK && z.avail_in == 0 && fed >= len && z.avail_out != 0) { inflateEnd(&z); return false; }   // truncated
 		}
-		at += z.total_in;
+		at = fed - z.avail_in;                    // where this member ended
 		inflateEnd(&z);
 	}
 	return true;
@@ -50,14 +58,25 @@ bool gzipAll(const std::vector<uint8_t>& in, std::vector<uint8_t>& out)
 	z_stream z;
 	memset(&z, 0, sizeof(z));
 	if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-	out.resize(deflateBound(&z, in.size()) + 64);
-	z.next_in = const_cast<Bytef*>(in.data());
-	z.avail_in = (uInt)in.size();
-	z.next_out = out.data();
-	z.avail_out = (uInt)out.size();
-	int rc = deflate(&z, Z_FINISH);
-	if (rc != Z_STREAM_END) { deflateEnd(&z); return false; }
-	out.resize(z.total_out);
+	out.clear();
+	size_t fed = 0;
+	uint8_t buf[1 << 16];
+	int rc = Z_OK;
+	while (rc != Z_STREAM_END)
+	{
+		if (z.avail_in == 0 && fed < in.size())
+		{
+			const size_t piece = std::min<size_t>(in.size() - fed, 1u << 30);
+			z.next_in = const_cast<Bytef*>(in.data() + fed);
+			z.avail_in = (uInt)piece;
+			fed += piece;
+		}
+		z.next_out = buf;
+		z.avail_out = sizeof(buf);
+		rc = deflate(&z, fed >= in.size() ? Z_FINISH : Z_NO_FLUSH);
+		if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) { deflateEnd(&z); return false; }
+		out.insert(out.end(), buf, buf + (sizeof(buf) - z.avail_out));
+	}
 	deflateEnd(&z);
 	return true;
 }
