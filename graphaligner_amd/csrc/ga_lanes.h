@@ -1078,43 +1078,44 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		{
 			{ const uint64_t t2 = lap_clock(); st.laps[1] += t2 - lapT; lapT = t2; }
 			// ---- fast steps: inside the node (offset > 0), inside the slice (r > 0), both columns in the window ----
-			while (true)
+			// (the row masks and the current cell's score are carried from step to step: a step costs two cell values of the left column)
 			{
-				const int r = (int)(row - sIdx * W);
-				const bool fast = tracing && r > 0 && offset > wLo && offset <= wHi && len + 8 < L.cap_moves;
-				if (!GAL_ANY(fast)) break;
-				if (fast)
+				int r = (int)(row - sIdx * W);
+				uint64_t mR = r < 0 ? 0ull : r < 63 ? ~(~0ull << (r + 1)) : ~0ull;      // rows 0 .. r
+				uint64_t mU = r <= 0 ? 0ull : ~(~0ull << r);                               // rows 0 .. r - 1
+				int here = q0.before + __builtin_popcountll(q0.vp & mR) - __builtin_popcountll(q0.vn & mR);
+				while (true)
 				{
-					const uint64_t mR = r < 63 ? ~(~0ull << (r + 1)) : ~0ull, mU = ~(~0ull << r);      // rows 0 .. r, rows 0 .. r - 1
-					const int here = q0.before + __builtin_popcountll(q0.vp & mR) - __builtin_popcountll(q0.vn & mR);
-					const int horizontal = q1.before + __builtin_popcountll(q1.vp & mR) - __builtin_popcountll(q1.vn & mR);
-					const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
-					const bool match = ((e[base] >> r) & 1) != 0;
-					int res;
-					if (horizontal < here - 1) res = -1;
-					else if (horizontal == here - 1) res = 1;
-					else
+					const bool fast = tracing && r > 0 && offset > wLo && offset <= wHi && len + 8 < L.cap_moves;
+					if (!GAL_ANY(fast)) break;
+					if (fast)
 					{
+						const int horizontal = q1.before + __builtin_popcountll(q1.vp & mR) - __builtin_popcountll(q1.vn & mR);
 						const int diagonal = q1.before + __builtin_popcountll(q1.vp & mU) - __builtin_popcountll(q1.vn & mU);
-						const int want = match ? here : here - 1;
-						res = diagonal < want ? -1 : diagonal == want ? 2 : 0;
-					}
-					if (res == 0)
-					{
-						const int up = q0.before + __builtin_popcountll(q0.vp & mU) - __builtin_popcountll(q0.vn & mU);
-						res = up == here - 1 ? 3 : -1;                           // assert(false) (:588)
-					}
-					if (res < 0) { status = GA_ASSERTION; tracing = false; }
-					else
-					{
-						if (res >= 2) row = row - 1;
-						if (res != 3)
+						const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
+						const int want = here - 1 + (int)((e[base] >> r) & 1);               // the diagonal cell's score if the step is diagonal
+						const bool left = horizontal == here - 1;
+						const bool diag = !left && diagonal == want;
+						bool bad = horizontal < here - 1 || (!left && diagonal < want);
+						int next = left ? horizontal : diagonal;
+						if (!left && !diag)
 						{
-							offset -= 1;
-							q0 = q1;
-							if (offset > wLo) winRead(offset - 1, q1);
+							next = q0.before + __builtin_popcountll(q0.vp & mU) - __builtin_popcountll(q0.vn & mU);
+							bad = bad || next != here - 1;                                     // assert(false) (:588)
 						}
-						putMove(res, 0);
+						if (bad) { status = GA_ASSERTION; tracing = false; }
+						else
+						{
+							here = next;
+							if (!left) { row = row - 1; r--; mR = mU; mU >>= 1; }
+							if (left || diag)
+							{
+								offset -= 1;
+								q0 = q1;
+								if (offset > wLo) winRead(offset - 1, q1);
+							}
+							putMove(left ? 1 : diag ? 2 : 3, 0);
+						}
 					}
 				}
 			}
