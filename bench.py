@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048, help="reads timed through the CPU oracle (0 = skip)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build with per-phase cycle stamps (not a timed build)")
     ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
+    ap.add_argument("--accuracy", type=int, default=256, help="reads scored against the simulator's true paths with the reference's criterion (CompareAlignments.cpp)")
     ap.add_argument("--check", type=int, default=64, help="reads compared with the oracle after the run (includes failed / later-pass reads)")
     args = ap.parse_args()
 
@@ -105,7 +106,8 @@ def main():
         # chr22-like density: ~1 SNP per 45 bp, short indels, 32-bp nodes
         g = synth.SynthGraph(synth.random_genome(args.genome, 47), node_len=args.node_len, snp_every=45, indel_every=500, seed=48)
     e_sub, e_ins, e_del = (float(x) for x in args.errors.split(","))
-    reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=e_sub, ins=e_ins, dele=e_del, seed=43 + 1000 * rank)
+    truth = []
+    reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=e_sub, ins=e_ins, dele=e_del, seed=43 + 1000 * rank, truth=truth)
     t_gen = time.time() - t0
     t0 = time.time()
     lib_path = entry.build_stamped() if args.stamps else args.lib
@@ -232,6 +234,14 @@ def main():
                 pc.compare_read(dict(d, trace=np.zeros((0, 7), dtype=np.int64)), dict(og.align(reads[i], [seeds[i]], args.bandwidth), trace=np.zeros((0, 7), dtype=np.int64)), "bench read %d" % i)
             out["detail"]["oracle_spot_check_reads"] = len(pick)
             out["detail"]["oracle_spot_check_failed_or_later_pass_reads"] = len(special)
+    if args.accuracy > 0:
+        # node-set overlap of predicted vs true path, good when >= 0.7 (CompareAlignments.cpp:13-44, 86)
+        from graphaligner_amd import compare
+        k = min(args.accuracy, len(reads))
+        some = graph.align(reads[:k], seeds[:k], args.bandwidth, 0)
+        sizes = {nid: len(seq) for nid, seq in g.nodes}
+        rep = compare.compare({"r%d" % i: truth[i] for i in range(k)}, {"r%d" % i: compare.predicted_nodes(r) for i, r in enumerate(some) if not r["failed"]}, sizes)
+        out["detail"]["accuracy"] = {"reads": k, "good_matches": rep["good"], "bad_matches": rep["bad"], "criterion": "node-set overlap >= 0.7 (CompareAlignments.cpp:86)"}
     if args.stamps:
         names = ["end_slice", "band+order", "trace_fast(in traceback)", "trace_general(in traceback)", "fill", "traceback", "trace_handover(in traceback)", "-"]
         tot = float(st["stamps"][0] + st["stamps"][1] + st["stamps"][4] + st["stamps"][5]) or 1.0

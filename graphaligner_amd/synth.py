@@ -66,6 +66,7 @@ class SynthGraph:
         self.node_at = np.zeros(n, dtype=np.int32)     # backbone position -> node id (ref allele path)
         self.node_off = np.zeros(n, dtype=np.int32)    # offset inside that node
         self._next_id = first_id
+        self.var_nodes = []      # per variant: (node ids of the reference allele, node ids of the alternative allele)
         tails = []
 
         def add_chain(seq_bytes, tails_in, backbone_start=None):
@@ -92,17 +93,21 @@ class SynthGraph:
         for (p, kind, ref_len, alt) in variants:
             if p > cur:
                 tails = [add_chain(genome[cur:p], tails, cur)]
+            id0 = self._next_id
             if kind == "snp":
                 r = add_chain(genome[p:p + 1], tails, p)
                 a = add_chain(alt, tails)
+                self.var_nodes.append(([r], [a]))
                 tails = [r, a]
                 cur = p + 1
             elif kind == "del":
                 d = add_chain(genome[p:p + ref_len], tails, p)
+                self.var_nodes.append((list(range(id0, self._next_id)), []))
                 tails = tails + [d]
                 cur = p + ref_len
             else:
                 i = add_chain(alt, tails)
+                self.var_nodes.append(([], list(range(id0, self._next_id))))
                 tails = tails + [i]
                 cur = p
         if cur < n:
@@ -124,7 +129,15 @@ class SynthGraph:
         return vg_bytes(self.nodes, self.edges, chunk_nodes)
 
     # ---- haplotypes & reads -----------------------------------------------------------------------
-    def haplotype_window(self, start, length, rng):
+    def _backbone_nodes(self, lo, hi, path):
+        if path is not None and hi > lo:
+            ids = self.node_at[lo:hi]
+            keep = np.concatenate([[True], ids[1:] != ids[:-1]])
+            for x in ids[keep]:
+                if not path or path[-1] != int(x):
+                    path.append(int(x))
+
+    def haplotype_window(self, start, length, rng, path=None):
         """bytes of one random haplotype starting at backbone position `start` (which must be a
         backbone/ref position), at least `length` long when the genome allows"""
         out = []
@@ -138,6 +151,7 @@ class SynthGraph:
             if nxt > cur:
                 take = min(nxt - cur, length - have)
                 out.append(self.genome[cur:cur + take])
+                self._backbone_nodes(cur, cur + take, path)
                 have += take
                 cur += take
                 if have >= length:
@@ -147,6 +161,8 @@ class SynthGraph:
             p, kind, ref_len, alt = self.variants[k]
             k += 1
             use_alt = rng.random() < 0.5
+            if path is not None:
+                path.extend(self.var_nodes[k - 1][1 if use_alt else 0])
             if kind == "snp":
                 out.append(alt if use_alt else self.genome[p:p + 1])
                 have += 1
@@ -203,8 +219,9 @@ def add_errors(seq, sub, ins, dele, rng):
     return np.concatenate(pieces)
 
 
-def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1, both_strands=True, mid_seed=False, min_part=2):
-    """returns (reads, seeds): reads are str, seeds are (bigraph node id, read position, reverse).
+def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1, both_strands=True, mid_seed=False, min_part=2, truth=None):
+    """returns (reads, seeds): reads are str, seeds are (bigraph node id, read position, reverse).  `truth`: a list that receives,
+    per read, the node ids of the walk it was drawn from (what SimulateReads.cpp writes as its truth GAM, :86-112).
     The seed names the node holding the read's first base (position 0) or, with mid_seed, the
     node holding the base at the middle of the read (exercises the backward extension)."""
     rng = np.random.default_rng(seed)
@@ -217,7 +234,8 @@ def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1
         if attempts > 50 * n_reads + 1000:
             raise RuntimeError("simulate_reads: cannot place %d reads of %d bp on this graph" % (n_reads, length))
         start = g._backbone_start(int(rng.integers(0, max(1, n - length - 1200))))
-        hap = g.haplotype_window(start, length, rng)
+        hpath = [] if truth is not None else None
+        hap = g.haplotype_window(start, length, rng, hpath)
         if len(hap) < length:
             continue
         reverse = both_strands and rng.random() < 0.5
@@ -229,49 +247,60 @@ def simulate_reads(graph, n_reads, length, sub=0.04, ins=0.04, dele=0.04, seed=1
                 half = length // 2
                 # first half = haplotype from start up to a backbone anchor, second half from it
                 anchor = g._backbone_start(start + half)
-                first = _hap_until(g, start, anchor, rng)
-                second = g.haplotype_window(anchor, length - half, rng)
+                p1 = [] if truth is not None else None
+                first = _hap_until(g, start, anchor, rng, p1)
+                second = g.haplotype_window(anchor, length - half, rng, p1)
                 a = add_errors(first, sub, ins, dele, rng)
                 b = add_errors(second, sub, ins, dele, rng)
                 if len(a) < min_part or len(b) < min_part:
                     continue
                 reads.append(np.concatenate([a, b]).tobytes().decode())
                 seeds.append((int(g.node_at[anchor]), len(a), False))
+                if truth is not None:
+                    truth.append(p1)
             else:
                 r = add_errors(hap, sub, ins, dele, rng)
                 if len(r) < min_part:
                     continue
                 reads.append(r.tobytes().decode())
                 seeds.append((int(g.node_at[start]), 0, False))
+                if truth is not None:
+                    truth.append(hpath)
         else:
             # walk forward from `start`, stop at a backbone anchor near start+length
             anchor = g._backbone_start(start + length)
             if anchor >= n - 1:
                 continue
-            body = _hap_until(g, start, anchor + 1, rng)     # includes the anchor base
+            bpath = [] if truth is not None else None
+            body = _hap_until(g, start, anchor + 1, rng, bpath)     # includes the anchor base
             if len(body) < min_part:
                 continue
             rc = revcomp_bytes(body)
             if mid_seed:
                 mid_anchor = g._backbone_start(start + length // 2)
-                left = _hap_until(g, start, mid_anchor + 1, rng)
-                right = _hap_until(g, mid_anchor + 1, anchor + 1, rng)
+                p2 = [] if truth is not None else None
+                left = _hap_until(g, start, mid_anchor + 1, rng, p2)
+                right = _hap_until(g, mid_anchor + 1, anchor + 1, rng, p2)
                 a = add_errors(revcomp_bytes(right), sub, ins, dele, rng)
                 b = add_errors(revcomp_bytes(left), sub, ins, dele, rng)
                 if len(a) < min_part or len(b) < min_part:
                     continue
                 reads.append(np.concatenate([a, b]).tobytes().decode())
                 seeds.append((int(g.node_at[mid_anchor]), len(a), True))
+                if truth is not None:
+                    truth.append(p2[::-1])
             else:
                 r = add_errors(rc, sub, ins, dele, rng)
                 if len(r) < min_part:
                     continue
                 reads.append(r.tobytes().decode())
                 seeds.append((int(g.node_at[anchor]), 0, True))
+                if truth is not None:
+                    truth.append(bpath[::-1])
     return reads, seeds
 
 
-def _hap_until(g, start, stop, rng):
+def _hap_until(g, start, stop, rng, path=None):
     """random haplotype covering backbone interval [start, stop) (both backbone positions)"""
     out = []
     cur = start
@@ -281,6 +310,7 @@ def _hap_until(g, start, stop, rng):
         nxt = min(nxt, stop)
         if nxt > cur:
             out.append(g.genome[cur:nxt])
+            g._backbone_nodes(cur, nxt, path)
             cur = nxt
             if cur >= stop:
                 break
@@ -291,6 +321,8 @@ def _hap_until(g, start, stop, rng):
             break
         k += 1
         use_alt = rng.random() < 0.5
+        if path is not None:
+            path.extend(g.var_nodes[k - 1][1 if use_alt else 0])
         if kind == "snp":
             out.append(alt if use_alt else g.genome[p:p + 1])
             cur = p + 1
