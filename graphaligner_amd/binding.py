@@ -63,7 +63,7 @@ class GaNamedSeed(C.Structure):
 EXPORTS = ["ga_graph_create", "ga_graph_destroy", "ga_graph_add_node", "ga_graph_add_edge", "ga_graph_add_bigraph_node",
            "ga_graph_add_bigraph_edge", "ga_graph_finalize", "ga_graph_load_gfa", "ga_graph_upload", "ga_graph_node_count", "ga_graph_bp",
            "ga_align_batch", "ga_results_free", "ga_batch_prepare", "ga_batch_run", "ga_batch_collect", "ga_batch_free", "ga_batch_stats",
-           "ga_graph_load_vg", "ga_gam_decode_seeds", "ga_results_encode_gam", "ga_bytes_free", "ga_status_string", "ga_version"]
+           "ga_graph_load_gfa_split", "ga_graph_split_lookup", "ga_results_unsplit", "ga_graph_load_vg", "ga_gam_decode_seeds", "ga_results_encode_gam", "ga_bytes_free", "ga_status_string", "ga_version"]
 
 _libs = {}
 
@@ -84,6 +84,9 @@ def load(path=None):
     L.ga_graph_add_bigraph_edge.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int]
     L.ga_graph_finalize.argtypes = [C.c_void_p, C.c_int]
     L.ga_graph_load_gfa.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ga_graph_load_gfa_split.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32]
+    L.ga_graph_split_lookup.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ga_results_unsplit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ga_graph_upload.argtypes = [C.c_void_p, C.c_int]
     L.ga_graph_node_count.argtypes = [C.c_void_p]
     L.ga_graph_node_count.restype = C.c_int64
@@ -115,14 +118,17 @@ def _check(L, s, what):
 class Graph:
     """AlignmentGraph built the way the reference's loaders build it, then copied to HBM"""
 
-    def __init__(self, nodes=None, edges=None, overlap=0, gfa=None, vg=None, device=0, lib_path=None):
+    def __init__(self, nodes=None, edges=None, overlap=0, gfa=None, vg=None, device=0, lib_path=None, split=0):
         self.L = load(lib_path)
         self.h = self.L.ga_graph_create()
         if vg is not None:
             _check(self.L, self.L.ga_graph_load_vg(self.h, vg, len(vg)), "ga_graph_load_vg")
         elif gfa is not None:
             data = gfa.encode() if isinstance(gfa, str) else gfa
-            _check(self.L, self.L.ga_graph_load_gfa(self.h, data, len(data)), "ga_graph_load_gfa")
+            if split:
+                _check(self.L, self.L.ga_graph_load_gfa_split(self.h, data, len(data), int(split)), "ga_graph_load_gfa_split")
+            else:
+                _check(self.L, self.L.ga_graph_load_gfa(self.h, data, len(data)), "ga_graph_load_gfa")
         else:
             for nid, seq in nodes:
                 b = seq.encode() if isinstance(seq, str) else seq
@@ -209,10 +215,18 @@ class Batch:
         finally:
             self.L.ga_results_free(out)
 
-    def collect(self, summary=False):
-        """summary=True: per-read numpy record array only (status, failed, score, n_mappings, ...), no Python lists"""
+    def collect(self, summary=False, unsplit=False):
+        """summary=True: per-read numpy record array only (status, failed, score, n_mappings, ...), no Python lists;
+        unsplit=True: results of a graph loaded with split=... on the nodes of the GFA file (ga_results_unsplit)"""
         out = C.POINTER(GaResults)()
         _check(self.L, self.L.ga_batch_collect(self.h, C.byref(out)), "ga_batch_collect")
+        if unsplit:
+            merged = C.POINTER(GaResults)()
+            try:
+                _check(self.L, self.L.ga_results_unsplit(self.g.h, out, C.byref(merged)), "ga_results_unsplit")
+            finally:
+                self.L.ga_results_free(out)
+            out = merged
         try:
             if summary:
                 R = out.contents

@@ -93,6 +93,9 @@ struct ga_graph
 	GaFlatGraph flat;
 	GaHmmTables hmm;
 	GaBackendGraph* device = nullptr;
+	// optional node splitting (ga_graph_load_gfa_split): piece bigraph id -> the node it was cut from
+	struct Piece { int64_t orig; uint64_t start, len, origLen; };
+	std::unordered_map<int64_t, Piece> pieces;
 
 	ga_graph()
 	{
@@ -488,7 +491,7 @@ int ga_graph_add_bigraph_edge(ga_graph_t* g, int64_t from, int fromStart, int64_
 }
 int ga_graph_finalize(ga_graph_t* g, int overlap) { return g ? finalizeGraph(g, overlap) : GA_E_INVALID; }
 
-int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len)
+static int loadGfa(ga_graph_t* g, const char* text, size_t len, uint32_t maxNodeLen)
 {
 	// DirectedGraph::StreamGFAGraphFromFile (BigraphToDigraph.cpp:137-189): three passes over the lines
 	if (!g || g->finalized) return GA_E_INVALID;
@@ -501,8 +504,10 @@ int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len)
 		i = e + 1;
 	}
 	int overlap = 0;
+	int64_t maxId = 0;
 	for (auto& l : lines)
 	{
+		if (l.first[0] == 'S' && maxNodeLen) { std::stringstream str(std::string(l.first, std::min<size_t>(l.second, 64))); std::string d; int64_t id = 0; str >> d >> id; maxId = std::max(maxId, id); }
 		if (l.first[0] != 'L') continue;
 		std::stringstream str(std::string(l.first, l.second));
 		std::string d1, d2, d3, d4, d5, ov;
@@ -512,6 +517,10 @@ int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len)
 		if (!(overlap == 0 || overlap == o)) return GA_E_INVALID;
 		overlap = o;
 	}
+	if (maxNodeLen && overlap != 0) return GA_E_INVALID;       // pieces of a node overlap by nothing: splitting is for blunt graphs
+	// first / last piece of every split node: the end an edge attaches to
+	std::unordered_map<int64_t, std::pair<int64_t, int64_t>> ends;
+	int64_t nextId = maxId + 1;
 	for (auto& l : lines)
 	{
 		if (l.first[0] != 'S') continue;
@@ -520,6 +529,23 @@ int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len)
 		int64_t id;
 		str >> d >> id >> seq;
 		if ((int)seq.size() <= overlap) return GA_E_INVALID;
+		if (maxNodeLen && seq.size() > maxNodeLen)
+		{
+			// a chain of pieces, the first keeping the node's id; the reverse strand's nodes follow from the pieces like any node's
+			int64_t prev = -1;
+			for (size_t at = 0; at < seq.size(); at += maxNodeLen)
+			{
+				const size_t n = std::min<size_t>(maxNodeLen, seq.size() - at);
+				const int64_t pid = at == 0 ? id : nextId++;
+				int st = ga_graph_add_bigraph_node(g, pid, seq.data() + at, n);
+				if (st) return st;
+				g->pieces[pid] = ga_graph::Piece{id, at, n, seq.size()};
+				if (prev >= 0) { st = ga_graph_add_bigraph_edge(g, prev, 0, pid, 0); if (st) return st; }
+				prev = pid;
+			}
+			ends[id] = std::make_pair(id, prev);
+			continue;
+		}
 		size_t keep = seq.size() - overlap;
 		int s = addNode(g, id * 2, seq.data(), keep, false);
 		if (s) return s;
@@ -535,10 +561,28 @@ int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len)
 		int64_t from, to;
 		str >> d >> from >> fs >> to >> te;
 		if ((fs != "+" && fs != "-") || (te != "+" && te != "-")) return GA_E_INVALID;
+		// an edge leaves `from` at its end ("+") or its start ("-") and enters `to` at its start ("+") or its end ("-")
+		auto ef = ends.find(from), et = ends.find(to);
+		if (ef != ends.end()) from = fs == "-" ? ef->second.first : ef->second.second;
+		if (et != ends.end()) to = te == "-" ? et->second.second : et->second.first;
 		int s = ga_graph_add_bigraph_edge(g, from, fs == "-", to, te == "-");
 		if (s) return s;
 	}
 	return finalizeGraph(g, overlap);
+}
+
+int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len) { return loadGfa(g, text, len, 0); }
+int ga_graph_load_gfa_split(ga_graph_t* g, const char* text, size_t len, uint32_t max_node_len) { return max_node_len ? loadGfa(g, text, len, max_node_len) : GA_E_INVALID; }
+
+int ga_graph_split_lookup(const ga_graph_t* g, int64_t bigraph_id, int64_t* orig_id, uint64_t* start, uint64_t* orig_len)
+{
+	if (!g) return GA_E_INVALID;
+	auto it = g->pieces.find(bigraph_id);
+	if (it == g->pieces.end()) { if (orig_id) *orig_id = bigraph_id; if (start) *start = 0; if (orig_len) *orig_len = 0; return 1; }
+	if (orig_id) *orig_id = it->second.orig;
+	if (start) *start = it->second.start;
+	if (orig_len) *orig_len = it->second.origLen;
+	return GA_S_OK;
 }
 
 int ga_graph_upload(ga_graph_t* g, int device)
@@ -918,6 +962,73 @@ void ga_results_free(ga_results_t* r)
 {
 	if (!r) return;
 	delete reinterpret_cast<ResultsOwner*>(r);     // `pub` is the owner's first member
+}
+
+// results over a graph loaded with ga_graph_load_gfa_split, expressed on the nodes of the GFA file: consecutive mappings on pieces of
+// one node become one mapping (lengths add up, the edit sequences are contiguous), offsets and trace items move to the node's coordinates
+int ga_results_unsplit(const ga_graph_t* g, const ga_results_t* in, ga_results_t** out)
+{
+	if (!g || !in || !out) return GA_E_INVALID;
+	ResultsOwner* R = new ResultsOwner();
+	R->edits.assign(in->edit_bytes, in->edit_bytes + in->n_edit_bytes);
+	auto piece = [&](int64_t digraphId) -> const ga_graph::Piece* {
+		auto it = g->pieces.find(digraphId / 2);
+		return it == g->pieces.end() ? nullptr : &it->second;
+	};
+	for (size_t i = 0; i < in->n_reads; i++)
+	{
+		ga_read_result_t rr = in->reads[i];
+		const size_t firstMap = R->mappings.size(), firstTrace = R->trace.size();
+		const ga_graph::Piece* prevPiece = nullptr;
+		for (uint64_t k = 0; k < rr.n_mappings; k++)
+		{
+			ga_mapping_t m = in->mappings[rr.first_mapping + k];
+			const ga_graph::Piece* p = piece(m.node_id);
+			if (p)
+			{
+				const bool rev = (m.node_id & 1) != 0;
+				if (R->mappings.size() > firstMap)
+				{
+					ga_mapping_t& last = R->mappings.back();
+					const bool adjacent = prevPiece && prevPiece->orig == p->orig && last.node_id == p->orig * 2 + (rev ? 1 : 0) &&
+					                      (rev ? p->start + p->len == prevPiece->start : prevPiece->start + prevPiece->len == p->start);
+					if (adjacent)
+					{
+						last.from_length += m.from_length;
+						last.to_length += m.to_length;
+						prevPiece = p;
+						continue;
+					}
+				}
+				if (k == 0) m.offset = (int64_t)(rev ? p->origLen - (p->start + p->len) : p->start) + m.offset;
+				m.node_id = p->orig * 2 + (rev ? 1 : 0);
+			}
+			prevPiece = p;
+			m.rank = (int32_t)(R->mappings.size() - firstMap);
+			R->mappings.push_back(m);
+		}
+		for (uint64_t k = 0; k < rr.n_trace; k++)
+		{
+			ga_trace_item_t t = in->trace[rr.first_trace + k];
+			auto it = g->pieces.find((int64_t)t.node_id);
+			if (it != g->pieces.end())
+			{
+				const ga_graph::Piece& p = it->second;
+				t.offset = (t.reverse ? p.origLen - (p.start + p.len) : p.start) + t.offset;
+				t.node_id = (int32_t)p.orig;
+			}
+			R->trace.push_back(t);
+		}
+		rr.first_mapping = firstMap; rr.n_mappings = R->mappings.size() - firstMap;
+		rr.first_trace = firstTrace; rr.n_trace = R->trace.size() - firstTrace;
+		R->reads.push_back(rr);
+	}
+	R->pub.n_reads = R->reads.size(); R->pub.reads = R->reads.data();
+	R->pub.n_mappings = R->mappings.size(); R->pub.mappings = R->mappings.data();
+	R->pub.n_edit_bytes = R->edits.size(); R->pub.edit_bytes = R->edits.data();
+	R->pub.n_trace = R->trace.size(); R->pub.trace = R->trace.data();
+	*out = &R->pub;
+	return GA_S_OK;
 }
 
 int ga_align_batch(const ga_graph_t* g, const ga_read_t* reads, size_t nReads, const ga_seed_t* seeds, const size_t* seedOffsets,

@@ -1421,7 +1421,9 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		wave_sync();
 	};
 
-	if (seedLen > L.cap_cols) status = GA_CAP_COLS;
+	// a seed node of >= 200 000 bp is the whole band of the second slice: the reference goes sparse there (GraphAligner.h:2483)
+	if (seedLen >= kCutoff) status = GA_UNSUPPORTED_BAND;
+	else if (seedLen > L.cap_cols) status = GA_CAP_COLS;
 	if (status == GA_OK) loadSeedState();
 	VI rowNext = load_lanes(rows, W, 0);
 	uint32_t rowNextSlice = 0;

@@ -834,6 +834,7 @@ template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m
 	// the traceback asserts samplingFrequency > 1 (:906) for fewer than four slices: such reads take the ladder, which reports it
 	if (st.numSlices < 4 || st.numSlices > L.max_slices) { st.status = GA_PUNT; return; }
 	const uint32_t seedLen = g_rec(L.graph, job.seed_node)[2];
+	if (seedLen >= kCutoff) { st.status = GA_UNSUPPORTED_BAND; return; }       // the second slice's band is this node: sparse method in the reference
 	if (seedLen > L.cap_cols || seedLen > 0xffffu) { st.status = GA_CAP_COLS; return; }
 	// initial slice: the whole seed node at score 0 (GraphAligner.h:2945-2960)
 	m.lds.wr(LY::P_NODE, job.seed_node);

@@ -61,6 +61,13 @@ int ga_graph_add_bigraph_edge(ga_graph_t* g, int64_t from, int from_start, int64
 int ga_graph_finalize(ga_graph_t* g, int dbg_overlap);
 /* DirectedGraph::StreamGFAGraphFromFile (BigraphToDigraph.cpp:137-189) over an in-memory GFA text; finalizes */
 int ga_graph_load_gfa(ga_graph_t* g, const char* text, size_t len);
+/* the same with every segment longer than max_node_len cut into a chain of pieces (the first keeps the segment's id, the others get new
+ * ids above the largest id of the file): the reference never splits nodes and leaves bands of >= 200 000 bp to its sparse method
+ * (GraphAlignerCommon.h:10), so a graph of long segments (a single-contig GFA) only reaches the bit-vector path when cut up.  Blunt
+ * graphs only (overlap 0).  This is an OPTION, not the reference's behaviour: alignments are those of the cut graph. */
+int ga_graph_load_gfa_split(ga_graph_t* g, const char* text, size_t len, uint32_t max_node_len);
+/* where a (bigraph) node id of a split graph comes from: 0 and (original id, start inside it, its length), or 1 when the id is not a piece */
+int ga_graph_split_lookup(const ga_graph_t* g, int64_t bigraph_id, int64_t* orig_id, uint64_t* start, uint64_t* orig_len);
 /* copy the flattened graph into the HBM of `device` (replicated per GPU; one process per GPU) */
 int ga_graph_upload(ga_graph_t* g, int device);
 int64_t ga_graph_node_count(const ga_graph_t* g);   /* AlignmentGraph::NodeSize, including the two dummy nodes */
@@ -130,6 +137,8 @@ typedef struct ga_results {
 int ga_align_batch(const ga_graph_t* g, const ga_read_t* reads, size_t n_reads, const ga_seed_t* seeds, const size_t* seed_offsets,
                    int initial_bandwidth, int ramp_bandwidth, uint32_t flags, ga_results_t** out);
 void ga_results_free(ga_results_t* r);
+/* results over a split graph (ga_graph_load_gfa_split) on the nodes of the GFA file: runs of pieces merged, offsets and trace items remapped */
+int ga_results_unsplit(const ga_graph_t* g, const ga_results_t* in, ga_results_t** out);
 
 /* staged form of the same call, for callers that keep inputs resident in HBM and for measurement:
  *   prepare = validate seeds, build extension jobs, upload reads;  run = the device work only;

@@ -156,3 +156,40 @@ def test_c5_shape_more_than_2_27_directed_nodes():
         edges = [(lo + 1 + j, False, lo + 2 + j, False) for j in range(hi - lo - 1)]
         og = ob.OracleGraph(nodes, edges)
         pc.compare_read(res[i], og.align(reads[i], [seeds[i]], 35), "C5 read %d" % i)
+
+
+def test_single_contig_gfa_needs_split_then_matches_oracle_of_cut_graph():
+    """a GFA with one 300 kbp segment.  Unsplit the first band already holds >= 200 000 bp, which the reference hands
+    to its sparse method (not built: GA_S_UNSUPPORTED_BAND); loaded with split=64 the bit-vector path applies, results equal the
+    oracle's on the hand-cut chain and ga_results_unsplit names the file's segment again."""
+    rng = np.random.default_rng(91)
+    n, cut = 300000, 64
+    contig = "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+    gfa = "H\tVN:Z:1.0\nS\t1\t%s\n" % contig
+    reads, seeds, starts = [], [], []
+    for k in range(96):
+        st = int(rng.integers(0, n - 6000)) // cut * cut
+        body = np.frombuffer(contig[st:st + 5000].encode(), dtype=np.uint8)
+        reads.append(synth.add_errors(body, 0.03, 0.03, 0.03, rng).tobytes().decode())
+        starts.append(st)
+    whole = binding.Graph(gfa=gfa)
+    res = whole.align(reads[:4], [(1, 0, False)] * 4, 35)
+    assert all(r["status"] == 2 and r["failed"] for r in res)              # UNSUPPORTED_BAND, loudly, not a wrong answer
+    pieces = [(1 if j == 0 else 1 + j, contig[j * cut:(j + 1) * cut]) for j in range((n + cut - 1) // cut)]
+    edges = [(pieces[j][0], False, pieces[j + 1][0], False) for j in range(len(pieces) - 1)]
+    split = binding.Graph(gfa=gfa, split=cut)
+    assert split.node_count == 2 * len(pieces) + 2
+    seeds = [(pieces[st // cut][0], 0, False) for st in starts]
+    b = split.prepare(reads, seeds, 35, 0, flags=binding.GA_F_TRACE)
+    b.run()
+    res = b.collect()
+    og = ob.OracleGraph(pieces, edges)
+    _properties(res, reads, seeds, len(reads))
+    for i in range(0, len(reads), 6):
+        pc.compare_read(res[i], og.align(reads[i], [seeds[i]], 35), "split read %d" % i)
+    merged = b.collect(unsplit=True)
+    for r, m, st in zip(res, merged, starts):
+        assert len(m["mappings"]) == 1 and m["mappings"][0][0] == 2 and m["score"] == r["score"]
+        assert m["mappings"][0][5] == sum(x[5] for x in r["mappings"])
+        assert abs(m["mappings"][0][2] - st) <= 64
+        assert (m["trace"][:, 0] == 1).all() and (np.diff(m["trace"][m["trace"][:, 4] != 5][:, 2].astype(np.int64)) >= 0).all()
