@@ -105,6 +105,13 @@ template <int R> GAL_FN uint64_t rec_off(uint32_t row, int lane)
 }
 
 // ---- per-lane LDS tables: word i of lane l sits at lds[i * LW + l] ------------------------------------------------
+#ifndef GAL_WINCAP
+#define GAL_WINCAP 24
+#endif
+#ifndef GAL_TOPUP
+#define GAL_TOPUP 4
+#endif
+constexpr int kStageWordsLane = 50;          // 32-bit words per lane of the staging image that follows the tables (64 lanes x kStageWords64 x 2 / 64)
 template <int N> struct Lay
 {
 	static constexpr int H = 2 * N;                   // heap entries
@@ -120,12 +127,15 @@ template <int N> struct Lay
 	static constexpr int OB_POST = 0, OB_COLOR = N, OB_STSLOT = 2 * N, OB_STCUR = 3 * N;
 	// during the traceback: node lists of the slice traced through and of the slice above it
 	static constexpr int T_CN = 0, T_CB = N, T_PN = 2 * N, T_PB = 3 * N;
-	static constexpr int T_WIN = 4 * N, T_WINCOLS = (6 * N) / 5 < 16 ? (6 * N) / 5 : 16;       // window of column records (5 words each)
-	static_assert(4 * N + T_WINCOLS * 5 <= 10 * N && T_WINCOLS >= 8, "traceback window does not fit");
+	// window of column records (5 words each): the rest of the tables and, behind them, the words of the staging image (kStageWordsLane
+	// per lane at any lane stride), which the traceback does not use
+	static constexpr int T_WIN = 4 * N, T_WINCOLS = (6 * N + kStageWordsLane) / 5 < GAL_WINCAP ? (6 * N + kStageWordsLane) / 5 : GAL_WINCAP;
+	static_assert(4 * N + T_WINCOLS * 5 <= 10 * N + kStageWordsLane && T_WINCOLS >= 8, "traceback window does not fit");
 	static constexpr int WORDS = 10 * N;
 	static_assert((2 * N + HB + 3) / 4 <= N, "hash bytes do not fit");
 };
 
+static_assert(kStageWordsLane == 50 && GAL_WINCAP <= 32, "kStageWords64 * 2; the window's bases are one 64-bit word");
 struct Lds
 {
 	uint32_t* base;     // already offset by the lane
@@ -1004,7 +1014,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		uint32_t slotRow = 0, recNode = 0xffffffffu, inDeg = 0;
 		uint32_t nb[4] = {0, 0, 0, 0}, nbLen[4] = {0, 0, 0, 0};
 		uint64_t firstCol = 0;
-		uint32_t wbases = 0;                          // the graph bases of the window's columns, 2 bits each from wLo up
+		uint64_t wbases = 0;                          // the graph bases of the window's columns, 2 bits each from wLo up
 		uint32_t wLo = 1, wHi = 0;                    // columns of `node` (in slice sIdx) the window holds: [wLo, wHi], empty when wLo > wHi
 		bool tracing = true;
 		auto winRead = [&](uint32_t o, Col& c) {
@@ -1029,7 +1039,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				slotRow = curRow + l.rd(tCB + slot);
 				wLo = 1; wHi = 0;
 			}
-			const bool refill = !(offset >= wLo && offset <= wHi) || (wLo > 0 && offset - wLo < 4);
+			const bool refill = !(offset >= wLo && offset <= wHi) || (wLo > 0 && offset - wLo < (uint32_t)GAL_TOPUP);
 			const uint32_t nLo = offset >= (uint32_t)(kWin - 1) ? offset - (uint32_t)(kWin - 1) : 0;
 			Col wc[kWin];
 			if (refill)
@@ -1053,7 +1063,8 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				{
 					const uint64_t col = firstCol + wLo;
 					const uint32_t* q = g.seq2 + (col >> 4);
-					wbases = (uint32_t)(((uint64_t)q[0] | ((uint64_t)q[1] << 32)) >> (2 * (uint32_t)(col & 15)));
+					const uint32_t sh = 2 * (uint32_t)(col & 15);
+					wbases = (((uint64_t)q[0] | ((uint64_t)q[1] << 32)) >> sh) | (sh ? (uint64_t)q[2] << (64 - sh) : 0ull);     // 32 columns
 				}
 #pragma unroll
 				for (int i = 0; i < kWin; i++)

@@ -73,7 +73,7 @@ struct EmulBatch : GaBackendBatch
 		L.initial_bw = cfg.initial_bw; L.ramp_bw = cfg.ramp_bw;
 		const WaveLayout lay = wave_layout<N>(capCols, capRows, cfg.max_slices, capMoves);
 		std::vector<uint8_t> scratch(lay.bytes + 256);
-		std::vector<uint32_t> lds((size_t)Lay<N>::WORDS * 64);
+		std::vector<uint32_t> lds((size_t)(Lay<N>::WORDS + kStageWordsLane) * 64);     // tables + the words of the staging image behind them
 		std::vector<LaneMem> mem(64);
 		std::vector<LaneState> st(64);
 		for (int lane = 0; lane < 64; lane++)
