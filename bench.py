@@ -243,10 +243,14 @@ def main():
         rep = compare.compare({"r%d" % i: truth[i] for i in range(k)}, {"r%d" % i: compare.predicted_nodes(r) for i, r in enumerate(some) if not r["failed"]}, sizes)
         out["detail"]["accuracy"] = {"reads": k, "good_matches": rep["good"], "bad_matches": rep["bad"], "criterion": "node-set overlap >= 0.7 (CompareAlignments.cpp:86)"}
     if args.stamps:
-        names = ["end_slice", "band+order", "trace_fast(in traceback)", "trace_general(in traceback)", "fill", "traceback", "trace_handover(in traceback)", "-"]
+        names = ["end_slice", "band+order", "trace_fast(in traceback)", "trace_general(in traceback)", "fill", "traceback", "trace_handover(in traceback)", "rounds|fast_iterations<<32"]
+        if os.environ.get("GA_STAMPS_LEVEL") == "2":      # the traceback's general step in parts instead of the slice phases
+            names[0], names[1], names[4] = "general:decide", "general:slice_change", "general:window"
+
         tot = float(st["stamps"][0] + st["stamps"][1] + st["stamps"][4] + st["stamps"][5]) or 1.0
         out["detail"]["phase_share"] = {n: round(v / tot, 4) for n, v in zip(names, st["stamps"])}
         out["detail"]["cycles_per_job"] = round(tot / max(1, st["n_jobs"]))
+        out["detail"]["stamps_raw"] = [int(v) for v in st["stamps"]]
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

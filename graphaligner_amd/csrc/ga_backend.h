@@ -4,6 +4,9 @@
 // device logic can be checked in the CPU-only container; that object is never part of the
 // shipped library.
 #pragma once
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <cstddef>
 #include <cstdint>
 #include <functional>
@@ -66,7 +69,9 @@ class GaBackendBatch
 public:
 	virtual ~GaBackendBatch() {}
 	virtual int run() = 0;                                                   // device work only; returns ga_status
-	virtual int fetch(std::vector<GaJobOut>& outs, std::vector<uint8_t>& traceBytes) = 0;     // moves of job i: traceBytes[outs[i].trace_off ..+trace_len)
+	// moves of job i: (*traceBytes)[outs[i].trace_off ..+trace_len); the bytes stay the backend's (valid until fetchDone or the next fetch)
+	virtual int fetch(std::vector<GaJobOut>& outs, const uint8_t** traceBytes, uint64_t* nBytes) = 0;
+	virtual void fetchDone() {}
 	virtual GaRunStats stats() const = 0;
 };
 
@@ -88,12 +93,27 @@ inline void ga_build_eq_words(const uint8_t* rows, uint64_t nRows, uint64_t* eq)
 		uint64_t e[4] = {0, 0, 0, 0};
 		uint32_t invalid = 0;
 		const uint8_t* r = rows + s * 64;
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+		// bit b of 16 codes at a time: shifted up to the bytes' sign bits, collected by movemask
+		__m128i any = _mm_setzero_si128();
+		for (int q = 0; q < 4; q++)
+		{
+			const __m128i v = _mm_loadu_si128((const __m128i*)(r + 16 * q));
+			any = _mm_or_si128(any, v);
+			e[0] |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_slli_epi16(v, 7)) << (16 * q);
+			e[1] |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_slli_epi16(v, 6)) << (16 * q);
+			e[2] |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_slli_epi16(v, 5)) << (16 * q);
+			e[3] |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_slli_epi16(v, 4)) << (16 * q);
+		}
+		invalid = (uint32_t)_mm_movemask_epi8(any);            // GA_ROW_INVALID is the codes' top bit
+#else
 		for (int i = 0; i < 64; i++)
 		{
 			const uint8_t c = r[i];
 			for (int b = 0; b < 4; b++) e[b] |= (uint64_t)((c >> b) & 1) << i;
 			invalid |= c & GA_ROW_INVALID;
 		}
+#endif
 		uint64_t* o = eq + s * 5;
 		o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = e[3];
 		o[4] = (uint64_t)((r[63] >> 4) & 7) | (invalid ? 8u : 0u);

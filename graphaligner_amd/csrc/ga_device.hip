@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/graphaligner_amd.h"
@@ -118,7 +120,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #undef GAL_LAP
 #ifdef GA_STAMPS
 		// diagnostic build: the wave's cycles per phase, booked on its first job (names in bench.py)
-		if (hasJob && lane == 0) { GaJobOut* o = L.outs + st.job; o->stamps[1] = acc[0]; o->stamps[4] = acc[1]; o->stamps[0] = acc[2]; o->stamps[5] = acc[3]; o->stamps[2] = st.laps[0]; o->stamps[3] = st.laps[1]; o->stamps[6] = st.laps[2]; }
+		if (hasJob && lane == 0) { GaJobOut* o = L.outs + st.job; o->stamps[1] = acc[0]; o->stamps[4] = acc[1]; o->stamps[0] = acc[2]; o->stamps[5] = acc[3]; o->stamps[2] = st.laps[0]; o->stamps[3] = st.laps[1]; o->stamps[6] = st.laps[2]; o->stamps[7] = st.laps[7];
+#if GA_STAMPS == 2
+			// second diagnostic layout: the parts of the traceback's general step instead of end_slice / band / fill
+			o->stamps[0] = st.laps[4]; o->stamps[1] = st.laps[5]; o->stamps[4] = st.laps[6];
+#endif
+		}
 #endif
 		__syncthreads();
 	}
@@ -136,7 +143,7 @@ struct DevGraph : GaBackendGraph
 	uint8_t* pool = nullptr;
 	size_t poolBytes = 0;
 	bool poolBusy = false;
-	~DevGraph() override { hipSetDevice(device); for (void* p : allocs) hipFree(p); if (pool) hipFree(pool); }
+	~DevGraph() override { hipSetDevice(device); for (void* p : allocs) hipFree(p); if (pool) hipFree(pool); if (hostPool) hipHostFree(hostPool); }
 	uint8_t* takePool(size_t bytes)
 	{
 		if (poolBusy) return nullptr;
@@ -151,6 +158,27 @@ struct DevGraph : GaBackendGraph
 		return pool;
 	}
 	void givePool() { poolBusy = false; }
+	// pinned host buffer for the moves on their way back (page-locking half a GB per batch would cost more than the copy)
+	std::mutex hostLock;
+	uint8_t* hostPool = nullptr;
+	size_t hostPoolBytes = 0;
+	bool hostPoolBusy = false;
+	uint8_t* takeHost(size_t bytes)
+	{
+		std::lock_guard<std::mutex> lock(hostLock);
+		if (hostPoolBusy) return nullptr;
+		if (bytes > hostPoolBytes)
+		{
+			if (hostPool) hipHostFree(hostPool);
+			hostPool = nullptr; hostPoolBytes = 0;
+			const size_t want = bytes + bytes / 8;
+			if (hipHostMalloc((void**)&hostPool, want, hipHostMallocDefault) != hipSuccess) { hostPool = nullptr; return nullptr; }
+			hostPoolBytes = want;
+		}
+		hostPoolBusy = true;
+		return hostPool;
+	}
+	void giveHost() { std::lock_guard<std::mutex> lock(hostLock); hostPoolBusy = false; }
 	template <typename T> int put(const std::vector<T>& v, const T** out)
 	{
 		void* p = nullptr;
@@ -186,6 +214,7 @@ struct DevBatch : GaBackendBatch
 	~DevBatch() override
 	{
 		hipSetDevice(g->device);
+		if (hostFromPool) g->giveHost();
 		for (void* p : allocs) hipFree(p);
 		if (privateScratch) hipFree(privateScratch);
 		if (evA) hipEventDestroy(evA);
@@ -444,17 +473,37 @@ struct DevBatch : GaBackendBatch
 		return rc;
 	}
 
-	int fetch(std::vector<GaJobOut>& o, std::vector<uint8_t>& traces) override
+	uint8_t* hostTraces = nullptr;       // the graph's pinned buffer (hostFromPool) or a private one
+	bool hostFromPool = false;
+	std::unique_ptr<uint8_t[]> hostPrivate;
+	size_t hostPrivateBytes = 0;
+	int fetch(std::vector<GaJobOut>& o, const uint8_t** traces, uint64_t* nBytes) override
 	{
 		HIP_OK(hipSetDevice(g->device));
+		fetchDone();
 		o = outs;
 		for (size_t i = 0; i < o.size(); i++) o[i].reserved2 = passOf[i];      // 0 = finished by the first pass
 		uint64_t top = 0;
 		HIP_OK(hipMemcpy(&top, L.trace_top, 8, hipMemcpyDeviceToHost));
 		top = std::min<uint64_t>(top, L.trace_pool_cap);
-		traces.resize(top);
-		if (top) HIP_OK(hipMemcpy(traces.data(), L.traces, top, hipMemcpyDeviceToHost));
+		hostTraces = g->takeHost(top + 64);
+		hostFromPool = hostTraces != nullptr;
+		if (!hostTraces)
+		{
+			// another batch of this graph is being assembled from the pinned buffer: pageable memory, not initialised first
+			if (hostPrivateBytes < top + 64) { hostPrivate.reset(new uint8_t[top + 64]); hostPrivateBytes = top + 64; }
+			hostTraces = hostPrivate.get();
+		}
+		if (top) HIP_OK(hipMemcpy(hostTraces, L.traces, top, hipMemcpyDeviceToHost));
+		*traces = hostTraces;
+		*nBytes = top;
 		return 0;
+	}
+	void fetchDone() override
+	{
+		if (hostFromPool) g->giveHost();
+		hostFromPool = false;
+		hostTraces = nullptr;
 	}
 	GaRunStats stats() const override { return st; }
 };

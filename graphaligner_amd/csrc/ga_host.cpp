@@ -28,6 +28,7 @@ constexpr int W = 64;
 struct CharTables
 {
 	uint8_t rowCode[256];    // bits 0-3: which of A,C,G,T the read char matches; bits 4-6: exact code; bit 7: not IUPAC
+	uint8_t rowCodeRc[256];  // rowCode of the complement
 	uint8_t complement[256]; // 0 = the reference's ReverseComplement asserts on this char
 	uint8_t baseCode[256];   // A0 C1 G2 T3, 255 otherwise
 	CharTables()
@@ -50,6 +51,7 @@ struct CharTables
 		const char* from = "ACTGNURYKMSWBVD";
 		const char* to = "TGACNAYRMKSWVBH";
 		for (int i = 0; from[i]; i++) { complement[(uint8_t)from[i]] = (uint8_t)to[i]; complement[(uint8_t)(from[i] + 32)] = (uint8_t)to[i]; }
+		for (int c = 0; c < 256; c++) rowCodeRc[c] = rowCode[complement[c]];
 	}
 };
 const CharTables& tables() { static const CharTables t; return t; }
@@ -612,15 +614,29 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	b->reads.resize(nReads);
 	b->names.resize(nReads);
 	b->seqs.resize(nReads);
+	const auto tp0 = std::chrono::steady_clock::now();
 	auto pad64 = [](uint64_t n) { return (n + W - 1) / W * W; };
 	// the jobs are planned first (sizes and offsets only); their row codes, one byte per read base, are written afterwards by all host threads
 	typedef ga_batch::RowFill RowFill;
 	std::vector<RowFill>& fills = b->fills;
 	uint64_t rowsTotal = 0;
+	{
+		// the batch keeps its own copy of the reads (the caller's buffers may go away before ga_batch_collect): copied on the host threads
+		size_t nThreads = std::thread::hardware_concurrency();
+		if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
+		nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 16), nReads / 256 + 1));
+		std::vector<std::thread> pool;
+		const size_t per = (nReads + nThreads - 1) / nThreads;
+		for (size_t t = 0; t < nThreads; t++)
+		{
+			const size_t lo = std::min(nReads, t * per), hi = std::min(nReads, lo + per);
+			if (lo < hi) pool.emplace_back([&, lo, hi]() { for (size_t i = lo; i < hi; i++) b->seqs[i].assign(reads[i].sequence, reads[i].length); });
+		}
+		for (auto& th : pool) th.join();
+	}
 	for (size_t i = 0; i < nReads; i++)
 	{
 		b->names[i] = reads[i].name ? reads[i].name : "";
-		b->seqs[i].assign(reads[i].sequence, reads[i].length);
 		const std::string& seq = b->seqs[i];
 		b->reads[i].firstSeed = b->seeds.size();
 		b->reads[i].nSeeds = seedOffsets[i + 1] - seedOffsets[i];
@@ -677,24 +693,33 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		b->cfg.max_slices = std::max(b->cfg.max_slices, j.n_rows / W);
 	}
 	b->rowsTotal = rowsTotal;
+	const auto tp1 = std::chrono::steady_clock::now();
 	b->eq.assign((rowsTotal / W + 1) * 5, 0);   // match words per slice for the lanes = reads kernel
 	forEachFill(b, [&](const RowFill& f, const std::string& seq) {
 		// 64 row codes at a time, straight into the slice's match words
 		const uint8_t padCode = T.rowCode[(uint8_t)'N'];
+		const uint8_t* fw = (const uint8_t*)seq.data() + f.pos;
+		const uint8_t* bw = (const uint8_t*)seq.data() + f.n - 1;
 		uint8_t buf[W];
 		for (uint64_t r0 = 0; r0 < f.padded; r0 += W)
 		{
-			for (uint64_t k = 0; k < (uint64_t)W; k++)
-			{
-				const uint64_t r = r0 + k;
-				buf[k] = r >= f.n ? padCode : f.backward ? T.rowCode[T.complement[(uint8_t)seq[f.n - 1 - r]]] : T.rowCode[(uint8_t)seq[f.pos + r]];
-			}
+			const uint64_t full = r0 + W <= f.n ? (uint64_t)W : r0 < f.n ? f.n - r0 : 0;
+			if (f.backward) for (uint64_t k = 0; k < full; k++) buf[k] = T.rowCodeRc[*(bw - (r0 + k))];
+			else for (uint64_t k = 0; k < full; k++) buf[k] = T.rowCode[fw[r0 + k]];
+			for (uint64_t k = full; k < (uint64_t)W; k++) buf[k] = padCode;
 			ga_build_eq_words(buf, W, b->eq.data() + (f.off + r0) / W * 5);
 		}
 	});
 	int status = GA_S_OK;
+	const auto tp2 = std::chrono::steady_clock::now();
 	b->dev = ga_backend_create_batch(g->device, [b]() -> const std::vector<uint8_t>& { buildRows(b); return b->rows; }, b->eq, b->jobs, b->cfg, &status);
 	if (!b->dev) { delete b; return status ? status : GA_E_DEVICE; }
+	if (getenv("GA_DEBUG_COLLECT"))
+	{
+		const auto tp3 = std::chrono::steady_clock::now();
+		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		fprintf(stderr, "graphaligner_amd: prepare: plan + copies %.1f ms, match words %.1f ms, device batch (alloc + upload) %.1f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
+	}
 	*out = b;
 	return GA_S_OK;
 }
@@ -731,9 +756,10 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	if (!b || !out || !b->dev || !b->ran) return GA_E_INVALID;
 	const ga_graph& g = *b->g;
 	std::vector<GaJobOut> outs;
-	std::vector<uint8_t> moves;
+	const uint8_t* moves = nullptr;
+	uint64_t nMoveBytes = 0;
 	const auto t0 = std::chrono::steady_clock::now();
-	int s = b->dev->fetch(outs, moves);
+	int s = b->dev->fetch(outs, &moves, &nMoveBytes);
 	if (s) return s;
 	const auto t1 = std::chrono::steady_clock::now();
 	b->columnUpdates = 0;
@@ -749,7 +775,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		Trace t;
 		const GaJobOut& o = outs[job];
 		if (o.n_valid == 0) return t;
-		const uint8_t* mv = moves.data() + o.trace_off;
+		const uint8_t* mv = moves + o.trace_off;
 		t.resize((size_t)o.trace_len + 1);
 		Pos p{o.start_node, o.start_offset, o.start_row};
 		size_t at = t.size() - 1;
@@ -899,6 +925,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		for (auto& th : pool) th.join();
 	}
 	for (const ResultsOwner& part : parts) for (const ga_read_result_t& rr : part.reads) b->columnUpdates += rr.column_updates;
+	b->dev->fetchDone();
 	const auto t2 = std::chrono::steady_clock::now();
 	// stitch the per-thread arrays: sizes first, then every part copies itself into place (rebased offsets) on its own thread
 	{
@@ -951,7 +978,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	{
 		const auto t3 = std::chrono::steady_clock::now();
 		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-		fprintf(stderr, "graphaligner_amd: collect: fetch %.1f ms (%zu trace bytes), assembly %.1f ms on %zu threads, stitch %.1f ms\n", ms(t0, t1), moves.size(), ms(t1, t2), nThreads, ms(t2, t3));
+		fprintf(stderr, "graphaligner_amd: collect: fetch %.1f ms (%zu trace bytes), assembly %.1f ms on %zu threads, stitch %.1f ms\n", ms(t0, t1), (size_t)nMoveBytes, ms(t1, t2), nThreads, ms(t2, t3));
 	}
 	return GA_S_OK;
 }

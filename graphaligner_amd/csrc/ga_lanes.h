@@ -182,7 +182,7 @@ struct LaneState
 	uint64_t nColumns;
 	uint32_t rampUntil;
 	bool useRamp;
-	uint64_t laps[4];             // diagnostic builds: cycles inside the traceback (fast steps, general steps, hand-over)
+	uint64_t laps[8];             // diagnostic builds: cycles inside the traceback (fast steps, general steps, hand-over; [4..6] parts of the general step, [7] rounds | fast iterations << 32)
 };
 
 // ---- graph access ---------------------------------------------------------------------------------------------
@@ -832,7 +832,7 @@ template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m
 	st.nPushed = 0; st.nRun = 0; st.maxBandNodes = 0; st.kept = 0; st.nColumns = 0; st.rampUntil = 0; st.useRamp = false;
 	st.nRows = 0; st.numSlices = 0; st.seedNode = 0; st.eq = L.eq;
 	st.logCorrect = 0; st.logWrong = 0;
-	st.laps[0] = st.laps[1] = st.laps[2] = st.laps[3] = 0;
+	for (int i = 0; i < 8; i++) st.laps[i] = 0;
 	if (!hasJob) return;
 	const GaJob job = L.jobs[jobIndex];
 	st.nRows = job.n_rows;
@@ -1096,45 +1096,50 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				uint64_t mR = r < 0 ? 0ull : r < 63 ? ~(~0ull << (r + 1)) : ~0ull;      // rows 0 .. r
 				uint64_t mU = r <= 0 ? 0ull : ~(~0ull << r);                               // rows 0 .. r - 1
 				int here = q0.before + __builtin_popcountll(q0.vp & mR) - __builtin_popcountll(q0.vn & mR);
+				// (straight-line, predicated: a lane that cannot step keeps its state through the selects; the column after next is
+				// requested from the window one step ahead and only looked at when the step has moved a column left)
+				Col q2;
+				winRead((offset >= wLo + 2) & (offset <= wHi) ? offset - 2 : wLo, q2);
 				while (true)
 				{
-					const bool fast = tracing && r > 0 && offset > wLo && offset <= wHi && len + 8 < L.cap_moves;
+					const bool fast = tracing & (r > 0) & (offset > wLo) & (offset <= wHi) & (len + 8 < L.cap_moves);       // (& not &&: no branches)
 					if (!GAL_ANY(fast)) break;
-					if (fast)
-					{
-						const int horizontal = q1.before + __builtin_popcountll(q1.vp & mR) - __builtin_popcountll(q1.vn & mR);
-						const int diagonal = q1.before + __builtin_popcountll(q1.vp & mU) - __builtin_popcountll(q1.vn & mU);
-						const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
-						const int want = here - 1 + (int)((e[base] >> r) & 1);               // the diagonal cell's score if the step is diagonal
-						const bool left = horizontal == here - 1;
-						const bool diag = !left && diagonal == want;
-						bool bad = horizontal < here - 1 || (!left && diagonal < want);
-						int next = left ? horizontal : diagonal;
-						if (!left && !diag)
-						{
-							next = q0.before + __builtin_popcountll(q0.vp & mU) - __builtin_popcountll(q0.vn & mU);
-							bad = bad || next != here - 1;                                     // assert(false) (:588)
-						}
-						if (bad) { status = GA_ASSERTION; tracing = false; }
-						else
-						{
-							here = next;
-							if (!left) { row = row - 1; r--; mR = mU; mU >>= 1; }
-							if (left || diag)
-							{
-								offset -= 1;
-								q0 = q1;
-								if (offset > wLo) winRead(offset - 1, q1);
-							}
-							putMove(left ? 1 : diag ? 2 : 3, 0);
-						}
-					}
+#ifdef GA_STAMPS
+					st.laps[7] += 1ull << 32;
+#endif
+					const int horizontal = q1.before + __builtin_popcountll(q1.vp & mR) - __builtin_popcountll(q1.vn & mR);
+					const int diagonal = q1.before + __builtin_popcountll(q1.vp & mU) - __builtin_popcountll(q1.vn & mU);
+					const int up = q0.before + __builtin_popcountll(q0.vp & mU) - __builtin_popcountll(q0.vn & mU);
+					const int base = (int)(wbases >> (2 * ((offset - wLo) & 31))) & 3;
+					const int want = here - 1 + (int)((e[base] >> (r & 63)) & 1);      // the diagonal cell's score if the step is diagonal
+					const bool left = horizontal == here - 1;
+					const bool diag = !left & (diagonal == want);
+					// the reference's asserts on the way (:557-588): a neighbour below what the recurrence allows, or no predecessor at all
+					const bool bad = (horizontal < here - 1) | (!left & (diagonal < want)) | (!left & !diag & (up != here - 1));
+					const bool ok = fast & !bad;
+					status = fast & bad ? GA_ASSERTION : status;
+					tracing = tracing & !(fast & bad);
+					const bool colMove = ok & (left | diag), rowMove = ok & !left;
+					here = ok ? (left ? horizontal : diag ? diagonal : up) : here;
+					row -= rowMove ? 1u : 0u;
+					r -= rowMove ? 1 : 0;
+					mR = rowMove ? mU : mR;
+					mU = rowMove ? mU >> 1 : mU;
+					offset -= colMove ? 1u : 0u;
+					q0.vp = colMove ? q1.vp : q0.vp; q0.vn = colMove ? q1.vn : q0.vn; q0.before = colMove ? q1.before : q0.before;
+					q1.vp = colMove ? q2.vp : q1.vp; q1.vn = colMove ? q2.vn : q1.vn; q1.before = colMove ? q2.before : q1.before;
+					winRead((offset >= wLo + 2) & (offset <= wHi) ? offset - 2 : wLo, q2);
+					if (ok) putMove(left ? 1 : diag ? 2 : 3, 0);
 				}
 			}
 			{ const uint64_t t2 = lap_clock(); st.laps[0] += t2 - lapT; lapT = t2; }
 			// ---- the general step, for every lane still tracing (none of them can take a fast step) ----
+#ifdef GA_STAMPS
+			st.laps[7] += 1;
+#endif
 			if (tracing)
 			{
+				const uint64_t g0 = lap_clock();
 				if (row == 0xffffffffu) { tracing = false; continue; }               // reached the row before the first one
 				if (len + 8 >= L.cap_moves) { status = GA_CAP_TRACE; tracing = false; continue; }
 				if (inDeg > 4) { status = GA_PUNT; tracing = false; continue; }
@@ -1208,6 +1213,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				// put the move away (the step onto the row before the first one is not part of the trace, :949-950)
 				if (row == 0xffffffffu) { tracing = false; continue; }
 				putMove(res, via);
+				const uint64_t g1 = lap_clock();
 				if (res >= 2 && r == 0)
 				{
 					// stepped into the slice above
@@ -1221,7 +1227,9 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					loadEq(sIdx);
 					needSetup = true;
 				}
+				const uint64_t g2 = lap_clock();
 				ensure();
+				{ const uint64_t g3 = lap_clock(); st.laps[4] += g1 - g0; st.laps[5] += g2 - g1; st.laps[6] += g3 - g2; }
 			}
 		}
 #undef GAL_ANY

@@ -162,10 +162,11 @@ struct EmulBatch : GaBackendBatch
 		if (getenv("GA_EMUL_DEBUG")) { int hist[100] = {0}; for (auto& o : outs) hist[o.status < 100 ? o.status : 99]++; fprintf(stderr, "emul: %zu jobs, %llu finished by the lanes program, %llu retried; final statuses:", jobs.size(), (unsigned long long)lanesDone, (unsigned long long)retried); for (int i = 0; i < 100; i++) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]); fprintf(stderr, "\n"); }
 		return 0;
 	}
-	int fetch(std::vector<GaJobOut>& o, std::vector<uint8_t>& traces) override
+	int fetch(std::vector<GaJobOut>& o, const uint8_t** traces, uint64_t* nBytes) override
 	{
 		o = outs;
-		traces.assign(pool.begin(), pool.begin() + poolTop);
+		*traces = pool.data();
+		*nBytes = poolTop;
 		return 0;
 	}
 	GaRunStats stats() const override { GaRunStats s; s.jobs_retried = retried; s.slots = 1; return s; }
