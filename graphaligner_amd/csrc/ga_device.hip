@@ -101,6 +101,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 		m.moves = (uint32_t*)(base + lay.moves) + lane;
 		m.arena = base + lay.arena;
 		LaneState st;
+#if GA_STAMPS == 3
+		const uint64_t wall0 = wall_clock64(), cyc0 = gaw::stamp();
+#endif
 		uint64_t tA = gaw::stamp(), tB, acc[4] = {0, 0, 0, 0};
 #define GAL_LAP(i) do { tB = gaw::stamp(); acc[i] += tB - tA; tA = tB; } while (0)
 		lane_begin<N>(L, m, st, jobIndex, hasJob);
@@ -121,6 +124,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #ifdef GA_STAMPS
 		// diagnostic build: the wave's cycles per phase, booked on its first job (names in bench.py)
 		if (hasJob && lane == 0) { GaJobOut* o = L.outs + st.job; o->stamps[1] = acc[0]; o->stamps[4] = acc[1]; o->stamps[0] = acc[2]; o->stamps[5] = acc[3]; o->stamps[2] = st.laps[0]; o->stamps[3] = st.laps[1]; o->stamps[6] = st.laps[2]; o->stamps[7] = st.laps[7];
+#if GA_STAMPS == 3
+			// third diagnostic layout: when the wave ran, on the constant 100 MHz clock, and how many shader cycles that was
+			o->stamps[0] = wall0; o->stamps[1] = wall_clock64(); o->stamps[4] = gaw::stamp() - cyc0;
+#endif
 #if GA_STAMPS == 2
 			// second diagnostic layout: the parts of the traceback's general step instead of end_slice / band / fill
 			o->stamps[0] = st.laps[4]; o->stamps[1] = st.laps[5]; o->stamps[4] = st.laps[6];
@@ -365,6 +372,15 @@ struct DevBatch : GaBackendBatch
 			rc = afterPass(ms);
 			if (first) { st.main_ms = ms; st.main_variant = N * 1000 + 80 + (LW == 64 ? 0 : 1); st.slots = waves; st.waves_per_cu = wavesPerCu; st.scratch_bytes = (uint64_t)waves * lay.bytes; }
 			if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: lanes pass <%d,%d>: %zu jobs on %u waves (%.1f GB scratch), %.2f ms\n", N, LW, list.size(), waves, waves * (double)lay.bytes / 1e9, ms);
+#if GA_STAMPS == 3
+			{
+				uint64_t lo = ~0ull, hi = 0, n = 0; double life = 0, cyc = 0, lateStart = 0;
+				for (auto& o : outs) if (o.stamps[1]) { lo = std::min(lo, o.stamps[0]); hi = std::max(hi, o.stamps[1]); }
+				for (auto& o : outs) if (o.stamps[1]) { n++; life += (double)(o.stamps[1] - o.stamps[0]); cyc += (double)o.stamps[4]; lateStart = std::max(lateStart, (double)(o.stamps[0] - lo)); }
+				if (n) fprintf(stderr, "graphaligner_amd: %llu waves: first start to last end %.3f ms, mean wave life %.3f ms = %.1f M shader cycles (%.2f GHz), latest start %.3f ms after the first\n",
+				               (unsigned long long)n, (hi - lo) / 1e5, life / n / 1e5, cyc / n / 1e6, cyc / life / 1e4, lateStart / 1e5);
+			}
+#endif
 		}
 		if (fromPool) g->givePool();
 		return rc;

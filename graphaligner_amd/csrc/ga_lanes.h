@@ -523,7 +523,15 @@ template <int R> GAL_FN void rec_load(const LaneMem& m, uint32_t row, Col& c, ui
 	c.before = (int)(uint32_t)t;
 	endWord = (uint32_t)(t >> 32);
 }
-
+// (the traceback's form: no end word -- a requested word nobody looks at is a register the compiler hands out again at once, and
+// then has to wait for the request before it may write to it)
+template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c)
+{
+	const uint64_t* p = (const uint64_t*)(m.arena + rec_off<R>(row, m.lane));
+	c.vp = p[0];
+	c.vn = p[1];
+	c.before = (int)((const uint32_t*)p)[4];
+}
 
 #ifndef GA_EMULATE
 // the wave's 8 x 64 records of arena block `block` leave as twelve coalesced 1 KB stores: 16-byte chunk q of the 12 KB block
@@ -974,6 +982,19 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				for (int i = 0; i < 4; i++) if (k + (uint32_t)i < count) { l.wr(tn + (int)k + i, a[2 * i]); l.wr(tb + (int)k + i, a[2 * i + 1]); }
 			}
 		};
+		auto loadTableFrom = [&](int tn, int tb, uint32_t sl, uint32_t count, uint32_t from) {
+			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * 64;
+			for (uint32_t k = from; k < count; k++) { const uint32_t a0 = sn[(uint64_t)(2 * k) * 64], a1 = sn[(uint64_t)(2 * k + 1) * 64]; l.wr(tn + (int)k, a0); l.wr(tb + (int)k, a1); }
+		};
+		// what the traceback keeps of a node's graph record: first column, in-degree, first four in-neighbours with their lengths
+		struct NodeRec { uint64_t firstCol; uint32_t inDeg; uint32_t nb[4], nbLen[4]; };
+		auto loadRec = [&](uint32_t n, NodeRec& nr) {
+			const uint32_t* rec = g_rec(g, n);
+			nr.firstCol = ((uint64_t)rec[1] << 32) | rec[0];
+			nr.inDeg = rec[3] & 0xffffu;
+#pragma unroll
+			for (int k = 0; k < 4; k++) { nr.nb[k] = rec[8 + k]; nr.nbLen[k] = rec[12 + k]; }
+		};
 		loadHeader(sIdx, nN, curRow);
 		if (sIdx > 0) loadHeader(sIdx - 1, pN, prvRow);
 		if (sIdx > 1) loadHeader(sIdx - 2, aN, aRow);
@@ -993,8 +1014,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			const int sl = find_in(l, tn, (int)count, n);
 			c.vp = 0; c.vn = 0; c.before = 0;
 			if (sl < 0) return false;
-			uint32_t ew;
-			rec_load<8>(m, rowBase + l.rd(tb + sl) + off, c, ew);
+			rec_load_col<8>(m, rowBase + l.rd(tb + sl) + off, c);
 			return true;
 		};
 		uint32_t pack = 0;
@@ -1045,7 +1065,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			if (refill)
 			{
 #pragma unroll
-				for (int i = 0; i < kWin; i++) { uint32_t ew; wc[i].vp = 0; wc[i].vn = 0; wc[i].before = 0; if (nLo + (uint32_t)i <= offset) rec_load<8>(m, slotRow + nLo + (uint32_t)i, wc[i], ew); }
+				for (int i = 0; i < kWin; i++) { uint32_t ew; wc[i].vp = 0; wc[i].vn = 0; wc[i].before = 0; if (nLo + (uint32_t)i <= offset) rec_load_col<8>(m, slotRow + nLo + (uint32_t)i, wc[i]); (void)ew; }
 			}
 			if (needSetup && node != recNode)
 			{
@@ -1099,7 +1119,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				// (straight-line, predicated: a lane that cannot step keeps its state through the selects; the column after next is
 				// requested from the window one step ahead and only looked at when the step has moved a column left)
 				Col q2;
-				winRead((offset >= wLo + 2) & (offset <= wHi) ? offset - 2 : wLo, q2);
+				winRead(((offset >= wLo + 2) & (offset <= wHi)) ? offset - 2 : wLo, q2);
 				while (true)
 				{
 					const bool fast = tracing & (r > 0) & (offset > wLo) & (offset <= wHi) & (len + 8 < L.cap_moves);       // (& not &&: no branches)
@@ -1128,12 +1148,18 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					offset -= colMove ? 1u : 0u;
 					q0.vp = colMove ? q1.vp : q0.vp; q0.vn = colMove ? q1.vn : q0.vn; q0.before = colMove ? q1.before : q0.before;
 					q1.vp = colMove ? q2.vp : q1.vp; q1.vn = colMove ? q2.vn : q1.vn; q1.before = colMove ? q2.before : q1.before;
-					winRead((offset >= wLo + 2) & (offset <= wHi) ? offset - 2 : wLo, q2);
+					winRead(((offset >= wLo + 2) & (offset <= wHi)) ? offset - 2 : wLo, q2);
 					if (ok) putMove(left ? 1 : diag ? 2 : 3, 0);
 				}
 			}
 			{ const uint64_t t2 = lap_clock(); st.laps[0] += t2 - lapT; lapT = t2; }
 			// ---- the general step, for every lane still tracing (none of them can take a fast step) ----
+			// Two round trips to HBM per step of the wave: everything a lane has to see before it can decide (its window when the step
+			// left it, the in-neighbours' last columns at a node's first column, the columns of the slice above at a slice's first row,
+			// and the record of the first in-neighbour, where the path most likely goes) is requested together; after the decision, the
+			// new window, the tables of a new slice and the base words go together again.  Lanes that need nothing request a row that
+			// is always there: requests are wave-wide instructions either way, and a request behind a branch -- even a branch the whole
+			// wave takes together -- makes the compiler wait for everything outstanding where the branch ends.
 #ifdef GA_STAMPS
 			st.laps[7] += 1;
 #endif
@@ -1143,8 +1169,84 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				if (row == 0xffffffffu) { tracing = false; continue; }               // reached the row before the first one
 				if (len + 8 >= L.cap_moves) { status = GA_CAP_TRACE; tracing = false; continue; }
 				if (inDeg > 4) { status = GA_PUNT; tracing = false; continue; }
-				if (!(offset >= wLo && offset <= wHi && (offset == 0 || offset > wLo))) { ensure(); if (!tracing) continue; }
 				const int r = (int)(row - sIdx * W);
+				const uint32_t safeRow = 0;
+				const bool needWin = !(offset >= wLo && offset <= wHi && (offset == 0 || offset > wLo));
+				const bool atStart = offset == 0;
+				const bool atTop = r == 0 && sIdx > 0;
+				// (1) the window around the current column
+				Col wc[kWin];
+				uint32_t sq0 = 0, sq1 = 0, sq2 = 0;
+				const uint32_t nLoA = offset >= (uint32_t)(kWin - 1) ? offset - (uint32_t)(kWin - 1) : 0;
+				{
+#pragma unroll
+					for (int i = 0; i < kWin; i++) rec_load_col<8>(m, needWin && nLoA + (uint32_t)i <= offset ? slotRow + nLoA + (uint32_t)i : safeRow, wc[i]);
+					const uint64_t col = needWin ? firstCol + nLoA : 0ull;
+					const uint32_t* q = g.seq2 + (col >> 4);
+					sq0 = q[0]; sq1 = q[1]; sq2 = q[2];
+				}
+				// (2) the last columns of the in-neighbours in this slice, and the graph record of the first of them
+				Col nc[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++) { nc[k].vp = nc[k].vn = 0; nc[k].before = 0; }
+				bool nIn[4] = {false, false, false, false};
+				NodeRec spec = NodeRec();
+				uint32_t specNode = 0xffffffffu;
+				{
+					uint32_t nbRow[4];
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+					{
+						nbRow[k] = safeRow;
+						if (atStart && (uint32_t)k < inDeg)
+						{
+							const int sl = find_in(l, tCN, (int)nN, nb[k]);
+							if (sl >= 0) { nIn[k] = true; nbRow[k] = curRow + l.rd(tCB + sl) + nbLen[k] - 1; }
+						}
+					}
+#pragma unroll
+					for (int k = 0; k < 4; k++) rec_load_col<8>(m, nbRow[k], nc[k]);
+					if (atStart && inDeg > 0) specNode = nb[0];
+					loadRec(specNode != 0xffffffffu ? specNode : node, spec);
+				}
+				// (3) at a slice's first row: this column (U) and the column a diagonal step would reach (A) in the slice above
+				Col ca, cu;
+				ca.vp = ca.vn = 0; ca.before = 0; cu = ca;
+				bool aIn = false, uIn = false;
+				{
+					uint32_t rowA = safeRow, rowU = safeRow;
+					if (atTop)
+					{
+						const int slU = find_in(l, tPN, (int)pN, node);
+						if (slU >= 0) { uIn = true; rowU = prvRow + l.rd(tPB + slU) + offset; }
+						if (offset > 0) { aIn = uIn; rowA = uIn ? rowU - 1 : safeRow; }
+						else if (inDeg > 0)
+						{
+							const int slA = find_in(l, tPN, (int)pN, nb[0]);
+							if (slA >= 0) { aIn = true; rowA = prvRow + l.rd(tPB + slA) + nbLen[0] - 1; }
+						}
+					}
+					rec_load_col<8>(m, rowA, ca);
+					rec_load_col<8>(m, rowU, cu);
+				}
+				// ---- everything has arrived: the window first ----
+				if (needWin)
+				{
+					wLo = nLoA; wHi = offset;
+					const uint32_t sh = 2 * (uint32_t)((firstCol + wLo) & 15);
+					wbases = (((uint64_t)sq0 | ((uint64_t)sq1 << 32)) >> sh) | (sh ? (uint64_t)sq2 << (64 - sh) : 0ull);
+#pragma unroll
+					for (int i = 0; i < kWin; i++)
+					{
+						if (wLo + (uint32_t)i <= wHi)
+						{
+							const int at = tWIN + i * 5;
+							l.wr(at, (uint32_t)wc[i].vp); l.wr(at + 1, (uint32_t)(wc[i].vp >> 32)); l.wr(at + 2, (uint32_t)wc[i].vn); l.wr(at + 3, (uint32_t)(wc[i].vn >> 32)); l.wr(at + 4, (uint32_t)wc[i].before);
+						}
+					}
+					winRead(offset, q0);
+					if (offset > wLo) winRead(offset - 1, q1);
+				}
 				const int here = col_value(q0.vp, q0.vn, q0.before, r);
 				if (row == 0 && node == st.seedNode && (here == 0 || here == 1)) { row = 0xffffffffu; tracing = false; continue; }     // free start (:500)
 				const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
@@ -1166,7 +1268,12 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					}
 					return 0;
 				};
-				// value in the last row of the slice above (the all-zero seed slice before slice 0) of column (n, o)
+				// value in the last row of the slice above (the all-zero seed slice before slice 0) of a column requested above ...
+				auto aboveOf = [&](bool in, const Col& c, uint32_t n) -> int {
+					if (sIdx == 0) return n == st.seedNode ? 0 : big;
+					return in ? col_value(c.vp, c.vn, c.before, W - 1) : big;
+				};
+				// ... and of one that was not (in-neighbours after the first): its own round trip
 				auto valueAbove = [&](uint32_t n, uint32_t o) -> int {
 					if (sIdx == 0) return n == st.seedNode ? 0 : big;
 					Col c;
@@ -1175,11 +1282,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				};
 				if (curOffset == 0)
 				{
-					// the last columns of the in-neighbours in this slice: requested together, looked at in the reference's order
-					Col nc[4];
-					bool nIn[4];
-#pragma unroll
-					for (int k = 0; k < 4; k++) { nIn[k] = false; nc[k].vp = 0; nc[k].vn = 0; nc[k].before = 0; if ((uint32_t)k < inDeg) nIn[k] = recordIn(tCN, tCB, nN, curRow, nb[k], nbLen[k] - 1, nc[k]); }
+					// the in-neighbours, in the reference's order
 #pragma unroll
 					for (int k = 0; k < 4; k++)
 					{
@@ -1189,7 +1292,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 							via = k;
 							const int horizontal = nIn[k] ? col_value(nc[k].vp, nc[k].vn, nc[k].before, r) : big;
 							int diagonal = 0;
-							if (horizontal > here - 1) diagonal = r > 0 ? (nIn[k] ? col_value(nc[k].vp, nc[k].vn, nc[k].before, r - 1) : big) : valueAbove(nb[k], mo);
+							if (horizontal > here - 1) diagonal = r > 0 ? (nIn[k] ? col_value(nc[k].vp, nc[k].vn, nc[k].before, r - 1) : big) : k == 0 ? aboveOf(aIn, ca, nb[0]) : valueAbove(nb[k], mo);
 							res = decide(horizontal, diagonal, nb[k], mo);
 						}
 					}
@@ -1199,13 +1302,13 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				{
 					const int horizontal = col_value(q1.vp, q1.vn, q1.before, r);
 					int diagonal = 0;
-					if (horizontal > here - 1) diagonal = r > 0 ? col_value(q1.vp, q1.vn, q1.before, r - 1) : valueAbove(curNode, curOffset - 1);
+					if (horizontal > here - 1) diagonal = r > 0 ? col_value(q1.vp, q1.vn, q1.before, r - 1) : aboveOf(aIn, ca, curNode);
 					res = decide(horizontal, diagonal, curNode, curOffset - 1);
 				}
 				if (res < 0) { status = GA_ASSERTION; tracing = false; continue; }
 				if (res == 0)
 				{
-					const int up = r > 0 ? col_value(q0.vp, q0.vn, q0.before, r - 1) : valueAbove(curNode, curOffset);
+					const int up = r > 0 ? col_value(q0.vp, q0.vn, q0.before, r - 1) : aboveOf(uIn, cu, curNode);
 					if (up != here - 1) { status = GA_ASSERTION; tracing = false; continue; }              // assert(false) (:588)
 					row = row - 1;
 					res = 3;
@@ -1214,21 +1317,107 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				if (row == 0xffffffffu) { tracing = false; continue; }
 				putMove(res, via);
 				const uint64_t g1 = lap_clock();
-				if (res >= 2 && r == 0)
+				const bool changed = res >= 2 && r == 0;                                // stepped into the slice above
+				if (changed)
 				{
-					// stepped into the slice above
 					sIdx--;
 					int t = tCN; tCN = tPN; tPN = t;
 					t = tCB; tCB = tPB; tPB = t;
 					nN = pN; curRow = prvRow;
 					pN = aN; prvRow = aRow;
-					if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN);
-					if (sIdx > 1) loadHeader(sIdx - 2, aN, aRow);
-					loadEq(sIdx);
 					needSetup = true;
 				}
+				// ---- where the lane stands now: the node's columns in the slice, the window, a new node's record, a new slice's tables ----
+				if (needSetup)
+				{
+					const int slot = find_in(l, tCN, (int)nN, node);
+					if (slot < 0) { status = GA_ASSERTION; tracing = false; continue; }       // assert(slice.scores.hasNode(nodeIndex)) (:498)
+					slotRow = curRow + l.rd(tCB + slot);
+					wLo = 1; wHi = 0;
+				}
+				const bool refill = !(offset >= wLo && offset <= wHi) || (wLo > 0 && offset - wLo < (uint32_t)GAL_TOPUP);
+				const uint32_t nLo = offset >= (uint32_t)(kWin - 1) ? offset - (uint32_t)(kWin - 1) : 0;
+				const bool newNode = needSetup && node != recNode;
+				if (newNode && node == specNode)
+				{
+					firstCol = spec.firstCol; inDeg = spec.inDeg;
+#pragma unroll
+					for (int k = 0; k < 4; k++) { nb[k] = spec.nb[k]; nbLen[k] = spec.nbLen[k]; }
+					recNode = node;
+				}
+				const bool needRec = needSetup && node != recNode;
+				needSetup = false;
+				Col wd[kWin];
+				{
+#pragma unroll
+					for (int i = 0; i < kWin; i++) rec_load_col<8>(m, refill && nLo + (uint32_t)i <= offset ? slotRow + nLo + (uint32_t)i : safeRow, wd[i]);
+				}
+				const bool seqNow = refill && !needRec;
+				sq0 = sq1 = sq2 = 0;
+				{
+					const uint64_t col = seqNow ? firstCol + nLo : 0ull;
+					const uint32_t* q = g.seq2 + (col >> 4);
+					sq0 = q[0]; sq1 = q[1]; sq2 = q[2];
+				}
+				NodeRec fresh = NodeRec();
+				loadRec(node, fresh);
+				uint32_t tbl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hN = 0, hRow = 0;
+				uint64_t ne[4] = {0, 0, 0, 0};
+				{
+					// the slice above the new one: the first four entries of its node list here, the rest (wide bands) in the loop below
+					const uint32_t* sn = m.snodes + (uint64_t)(changed && sIdx > 0 ? sIdx - 1 : 0) * 2 * N * 64;
+#pragma unroll
+					for (int i = 0; i < 8; i++) tbl[i] = sn[(uint64_t)i * 64];
+					const uint32_t* h = m.hdr + (uint64_t)(changed && sIdx > 1 ? sIdx - 2 : 0) * kHdrWords * 64;
+					hN = h[0]; hRow = h[384];
+					const uint64_t* q = st.eq + (uint64_t)(changed ? sIdx : 0) * 5;
+					ne[0] = q[0]; ne[1] = q[1]; ne[2] = q[2]; ne[3] = q[3];
+				}
 				const uint64_t g2 = lap_clock();
-				ensure();
+				// ---- arrived ----
+				if (changed)
+				{
+					if (sIdx > 0)
+					{
+#pragma unroll
+						for (int i = 0; i < 4; i++) if ((uint32_t)i < pN) { l.wr(tPN + i, tbl[2 * i]); l.wr(tPB + i, tbl[2 * i + 1]); }
+						if (pN > 4) loadTableFrom(tPN, tPB, sIdx - 1, pN, 4);
+					}
+					if (sIdx > 1) { aN = hN; aRow = hRow; }
+					e[0] = ne[0]; e[1] = ne[1]; e[2] = ne[2]; e[3] = ne[3];
+				}
+				if (needRec)
+				{
+					firstCol = fresh.firstCol; inDeg = fresh.inDeg;
+#pragma unroll
+					for (int k = 0; k < 4; k++) { nb[k] = fresh.nb[k]; nbLen[k] = fresh.nbLen[k]; }
+					recNode = node;
+				}
+				if (GAL_ANY(refill && needRec))
+				{
+					// (a node entered through another in-neighbour than the first: its base words could only be requested now)
+					const uint64_t col = refill && needRec ? firstCol + nLo : 0ull;
+					const uint32_t* q = g.seq2 + (col >> 4);
+					const uint32_t t0 = q[0], t1 = q[1], t2 = q[2];
+					if (refill && needRec) { sq0 = t0; sq1 = t1; sq2 = t2; }
+				}
+				if (refill)
+				{
+					wLo = nLo; wHi = offset;
+					const uint32_t sh = 2 * (uint32_t)((firstCol + wLo) & 15);
+					wbases = (((uint64_t)sq0 | ((uint64_t)sq1 << 32)) >> sh) | (sh ? (uint64_t)sq2 << (64 - sh) : 0ull);
+#pragma unroll
+					for (int i = 0; i < kWin; i++)
+					{
+						if (wLo + (uint32_t)i <= wHi)
+						{
+							const int at = tWIN + i * 5;
+							l.wr(at, (uint32_t)wd[i].vp); l.wr(at + 1, (uint32_t)(wd[i].vp >> 32)); l.wr(at + 2, (uint32_t)wd[i].vn); l.wr(at + 3, (uint32_t)(wd[i].vn >> 32)); l.wr(at + 4, (uint32_t)wd[i].before);
+						}
+					}
+				}
+				winRead(offset, q0);
+				if (offset > wLo) winRead(offset - 1, q1);
 				{ const uint64_t g3 = lap_clock(); st.laps[4] += g1 - g0; st.laps[5] += g2 - g1; st.laps[6] += g3 - g2; }
 			}
 		}
