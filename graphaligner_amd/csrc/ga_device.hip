@@ -124,6 +124,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #ifdef GA_STAMPS
 		// diagnostic build: the wave's cycles per phase, booked on its first job (names in bench.py)
 		if (hasJob && lane == 0) { GaJobOut* o = L.outs + st.job; o->stamps[1] = acc[0]; o->stamps[4] = acc[1]; o->stamps[0] = acc[2]; o->stamps[5] = acc[3]; o->stamps[2] = st.laps[0]; o->stamps[3] = st.laps[1]; o->stamps[6] = st.laps[2]; o->stamps[7] = st.laps[7];
+#if GA_STAMPS == 4
+			// fourth diagnostic layout: the parts of the band phase in [0..4], the band phase in [6], the fill in [7]
+			o->stamps[6] = acc[0]; o->stamps[7] = acc[1];
+			for (int i = 0; i < 5; i++) o->stamps[i] = st.blaps[i];
+#endif
 #if GA_STAMPS == 3
 			// third diagnostic layout: when the wave ran, on the constant 100 MHz clock, and how many shader cycles that was
 			o->stamps[0] = wall0; o->stamps[1] = wall_clock64(); o->stamps[4] = gaw::stamp() - cyc0;

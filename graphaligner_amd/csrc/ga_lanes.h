@@ -182,6 +182,7 @@ struct LaneState
 	uint64_t nColumns;
 	uint32_t rampUntil;
 	bool useRamp;
+	uint64_t blaps[5];            // diagnostic builds: cycles inside the band phase (map order, previous band, heap, slots, processing order)
 	uint64_t laps[8];             // diagnostic builds: cycles inside the traceback (fast steps, general steps, hand-over; [4..6] parts of the general step, [7] rounds | fast iterations << 32)
 };
 
@@ -194,6 +195,51 @@ GAL_FN int find_in(const Lds& l, int table, int count, uint32_t key)
 	for (int k = 0; k < count; k++) if (l.rd(table + k) == key) found = found < 0 ? k : found;
 	return found;
 }
+// A node list of a narrow band (N <= 15) held in registers while the band is put together: a lookup is N compares instead of a
+// chain of LDS reads each waited for.  Entries past the count hold a value no node index has.
+constexpr uint32_t kNoNode = 0xffffffffu;
+template <int N> struct NodeRegs
+{
+	static constexpr bool kOn = N <= 15;
+	uint32_t v[kOn ? N : 1];
+	GAL_FN void load(const Lds& l, int table, int count)
+	{
+		if constexpr (kOn)
+		{
+#pragma unroll
+			for (int k = 0; k < N; k++) v[k] = l.rd(table + k);
+#pragma unroll
+			for (int k = 0; k < N; k++) v[k] = k < count ? v[k] : kNoNode;
+		}
+	}
+	GAL_FN void clear()
+	{
+		if constexpr (kOn)
+		{
+#pragma unroll
+			for (int k = 0; k < N; k++) v[k] = kNoNode;
+		}
+	}
+	GAL_FN void set(int at, uint32_t node)
+	{
+		if constexpr (kOn)
+		{
+#pragma unroll
+			for (int k = 0; k < N; k++) v[k] = k == at ? node : v[k];
+		}
+	}
+	GAL_FN int find(const Lds& l, int table, int count, uint32_t key) const
+	{
+		if constexpr (kOn)
+		{
+			int found = -1;
+#pragma unroll
+			for (int k = N - 1; k >= 0; k--) found = v[k] == key ? k : found;
+			return found;
+		}
+		else return find_in(l, table, count, key);
+	}
+};
 
 // ---- std::unordered_map<size_t,..> iteration order after inserting the previous band's nodes one by one --------
 // (NodeSlice.h:728-738 builds the frozen slice's map so; GraphAligner.h:1117 iterates it).  libstdc++: identity hash,
@@ -299,10 +345,16 @@ template <int N> GAL_FN int project_band(const GaDevGraph& g, const LaneMem& m, 
 	const int pn = st.pn, prevMin = st.prevMin, expand = bandwidth + W;
 	int cn = 0, heapSize = 0;
 	uint32_t totalCols = 0;
+	uint64_t bt = lap_clock();
+	NodeRegs<N> prevNodes, curNodes;
+	prevNodes.load(l, LY::P_NODE, pn);
+	curNodes.clear();
 	hash_order<N>(l, pn);
+	{ const uint64_t t2 = lap_clock(); st.blaps[0] += t2 - bt; bt = t2; }
 	auto add = [&](uint32_t node, int prevSlot, uint32_t len, uint32_t prevBase) -> int {
 		if (cn >= N) return GA_CAP_NODES;
 		if (len > 0xffffu || totalCols + len > 0xffffu) return GA_CAP_COLS;
+		curNodes.set(cn, node);
 		l.wr(LY::C_NODE + cn, node);
 		l.wr(LY::C_GEO + cn, totalCols | (len << 16));
 		l.wr(LY::C_PINFO + cn, prevSlot >= 0 ? (prevBase | ((uint32_t)prevSlot << 16)) : (kNone << 16));
@@ -344,14 +396,15 @@ template <int N> GAL_FN int project_band(const GaDevGraph& g, const LaneMem& m, 
 		if (rc != GA_OK) return rc;
 	}
 	if (cn == 0) return GA_ASSERTION;                                             // assert(distances.size() > 0) (:1138)
+	{ const uint64_t t2 = lap_clock(); st.blaps[1] += t2 - bt; bt = t2; }
 	while (heapSize > 0)
 	{
 		const uint32_t node = l.rd(LY::X_HEAPN);
 		const int prio = (int)l.rdh(LY::X_HEAPP, 0);
 		if (prio > expand) break;
 		heap_pop<N>(l, heapSize);
-		if (find_in(l, LY::C_NODE, cn, node) >= 0) continue;                      // already at a distance <= prio
-		const int ps = find_in(l, LY::P_NODE, pn, node);
+		if (curNodes.find(l, LY::C_NODE, cn, node) >= 0) continue;                // already at a distance <= prio
+		const int ps = prevNodes.find(l, LY::P_NODE, pn, node);
 		Rec6 rec;
 		loadRec6(node, rec);
 		const uint32_t len = rec.w[0];
@@ -362,6 +415,7 @@ template <int N> GAL_FN int project_band(const GaDevGraph& g, const LaneMem& m, 
 	}
 	st.cn = cn;
 	st.totalCols = totalCols;
+	{ const uint64_t t2 = lap_clock(); st.blaps[2] += t2 - bt; bt = t2; }
 	return GA_OK;
 }
 
@@ -381,6 +435,12 @@ template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, La
 		for (int i = 0; i < 9; i++) r[i] = rec[3 + i];
 	};
 	for (int i = 0; i < 9; i++) { cur[i] = 0; nxt[i] = 0; }
+	uint64_t bt = lap_clock();
+	constexpr bool kRegs = NodeRegs<N>::kOn;          // narrow bands: node lists, out-neighbour slots and the DFS state stay in registers
+	NodeRegs<N> curNodes, prevNodes;
+	curNodes.load(l, LY::C_NODE, cn);
+	prevNodes.load(l, LY::P_NODE, pn);
+	uint64_t outAll[4] = {0, 0, 0, 0};                // kRegs: 4 out-neighbour slots of 4 bits (15 = none) per node, 4 nodes per word
 	if (cn > 0) loadRec9(0, cur);
 	for (int s = 0; s < cn; s++)
 	{
@@ -390,55 +450,113 @@ template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, La
 		for (int i = 0; i < 9; i++) { rec[3 + i] = cur[i]; cur[i] = nxt[i]; }
 		const uint32_t outDeg = rec[3] >> 16, inDeg = rec[3] & 0xffffu;
 		if (outDeg > 4 || inDeg > 4) return GA_PUNT;
-		uint32_t slots = 0, inCur = 0, inPrv = 0;
+		uint32_t slots = 0, inCur = 0, inPrv = 0, nibbles = 0;
 #pragma unroll
 		for (uint32_t e = 0; e < 4; e++)
 		{
 			int x = -1, ic = -1, ip = -1;
-			if (e < outDeg) x = find_in(l, LY::C_NODE, cn, rec[4 + e]);
-			if (e < inDeg) { ic = find_in(l, LY::C_NODE, cn, rec[8 + e]); ip = find_in(l, LY::P_NODE, pn, rec[8 + e]); }
+			if (e < outDeg) x = curNodes.find(l, LY::C_NODE, cn, rec[4 + e]);
+			if (e < inDeg) { ic = curNodes.find(l, LY::C_NODE, cn, rec[8 + e]); ip = prevNodes.find(l, LY::P_NODE, pn, rec[8 + e]); }
 			slots |= (x < 0 ? kNone : (uint32_t)x) << (8 * e);
+			nibbles |= (x < 0 ? 15u : (uint32_t)x) << (4 * e);
 			inCur |= (ic < 0 ? kNone : (uint32_t)ic) << (8 * e);
 			inPrv |= (ip < 0 ? kNone : (uint32_t)ip) << (8 * e);
 		}
-		l.wr(LY::C_OUT + s, slots);
+		if constexpr (kRegs)
+		{
+			const uint64_t field = (uint64_t)nibbles << (16 * (s & 3));
+#pragma unroll
+			for (int w = 0; w < 4; w++) outAll[w] |= (s >> 2) == w ? field : 0ull;
+		}
+		else
+		{
+			l.wr(LY::C_OUT + s, slots);
+			l.wrb(LY::X_ORD, LY::OB_COLOR + s, 0);
+		}
 		// where the node's in-neighbours sit in the current / the previous band: read once when the fill starts the node
 		// (P_PACK is free by now; C_MIN[s] is only written when node s is finished)
 		l.wr(LY::P_PACK + s, inCur);
 		l.wr(LY::C_MIN + s, inPrv);
-		l.wrb(LY::X_ORD, LY::OB_COLOR + s, 0);
 	}
 	int emitted = 0;
-	for (int root = 0; root < cn; root++)
+	{ const uint64_t t2 = lap_clock(); st.blaps[3] += t2 - bt; bt = t2; }
+	if constexpr (kRegs)
 	{
-		if (l.rdb(LY::X_ORD, LY::OB_COLOR + root) != 0) continue;
-		int sp = 1;
-		l.wrb(LY::X_ORD, LY::OB_COLOR + root, 1);
-		l.wrb(LY::X_ORD, LY::OB_STSLOT, (uint32_t)root);
-		l.wrb(LY::X_ORD, LY::OB_STCUR, 0);
-		while (sp > 0)
+		// the same depth-first search with its state in registers: colour 2 bits per slot, the stack's slots and edge cursors 4 bits per level
+		uint32_t color = 0;
+		uint64_t stSlot = 0, stCur = 0;
+		int sp = 0, root = 0;
+		while (true)
 		{
-			const int v = (int)l.rdb(LY::X_ORD, LY::OB_STSLOT + sp - 1);
-			const int cur = (int)l.rdb(LY::X_ORD, LY::OB_STCUR + sp - 1);
-			if (cur < 4)
+			if (sp == 0)
 			{
-				const uint32_t x = (l.rd(LY::C_OUT + v) >> (8 * cur)) & 0xffu;
-				const uint32_t color = x == kNone ? 2u : l.rdb(LY::X_ORD, LY::OB_COLOR + (int)x);
-				if (color == 2) { l.wrb(LY::X_ORD, LY::OB_STCUR + sp - 1, (uint32_t)(cur + 1)); continue; }
-				if (color == 1) return GA_UNSUPPORTED_CYCLE;
-				l.wrb(LY::X_ORD, LY::OB_COLOR + (int)x, 1);
-				l.wrb(LY::X_ORD, LY::OB_STSLOT + sp, x);
-				l.wrb(LY::X_ORD, LY::OB_STCUR + sp, 0);
+				if (root >= cn) break;
+				if (((color >> (2 * root)) & 3u) == 0)
+				{
+					color |= 1u << (2 * root);
+					stSlot = (uint64_t)root; stCur = 0;
+					sp = 1;
+				}
+				root++;
+				continue;
+			}
+			const int t = 4 * (sp - 1);
+			const int v = (int)(stSlot >> t) & 15;
+			const int c = (int)(stCur >> t) & 15;
+			if (c < 4)
+			{
+				const uint64_t word = (v >> 2) == 0 ? outAll[0] : (v >> 2) == 1 ? outAll[1] : (v >> 2) == 2 ? outAll[2] : outAll[3];
+				const uint32_t x = (uint32_t)(word >> (16 * (v & 3) + 4 * c)) & 15u;
+				const uint32_t colx = x == 15u ? 2u : (color >> (2 * x)) & 3u;
+				if (colx == 2) { stCur += 1ull << t; continue; }
+				if (colx == 1) return GA_UNSUPPORTED_CYCLE;
+				color |= 1u << (2 * x);
+				stSlot = (stSlot & ~(15ull << (t + 4))) | ((uint64_t)x << (t + 4));
+				stCur &= ~(15ull << (t + 4));
 				sp++;
 				continue;
 			}
-			l.wrb(LY::X_ORD, LY::OB_COLOR + v, 2);
+			color = (color & ~(3u << (2 * v))) | (2u << (2 * v));
 			l.wrb(LY::X_ORD, LY::OB_POST + emitted, (uint32_t)v);
 			emitted++;
 			sp--;
-			if (sp > 0) l.wrb(LY::X_ORD, LY::OB_STCUR + sp - 1, l.rdb(LY::X_ORD, LY::OB_STCUR + sp - 1) + 1);
+			if (sp > 0) stCur += 1ull << (t - 4);
 		}
 	}
+	else
+	{
+		for (int root = 0; root < cn; root++)
+		{
+			if (l.rdb(LY::X_ORD, LY::OB_COLOR + root) != 0) continue;
+			int sp = 1;
+			l.wrb(LY::X_ORD, LY::OB_COLOR + root, 1);
+			l.wrb(LY::X_ORD, LY::OB_STSLOT, (uint32_t)root);
+			l.wrb(LY::X_ORD, LY::OB_STCUR, 0);
+			while (sp > 0)
+			{
+				const int v = (int)l.rdb(LY::X_ORD, LY::OB_STSLOT + sp - 1);
+				const int cur = (int)l.rdb(LY::X_ORD, LY::OB_STCUR + sp - 1);
+				if (cur < 4)
+				{
+					const uint32_t x = (l.rd(LY::C_OUT + v) >> (8 * cur)) & 0xffu;
+					const uint32_t color = x == kNone ? 2u : l.rdb(LY::X_ORD, LY::OB_COLOR + (int)x);
+					if (color == 2) { l.wrb(LY::X_ORD, LY::OB_STCUR + sp - 1, (uint32_t)(cur + 1)); continue; }
+					if (color == 1) return GA_UNSUPPORTED_CYCLE;
+					l.wrb(LY::X_ORD, LY::OB_COLOR + (int)x, 1);
+					l.wrb(LY::X_ORD, LY::OB_STSLOT + sp, x);
+					l.wrb(LY::X_ORD, LY::OB_STCUR + sp, 0);
+					sp++;
+					continue;
+				}
+				l.wrb(LY::X_ORD, LY::OB_COLOR + v, 2);
+				l.wrb(LY::X_ORD, LY::OB_POST + emitted, (uint32_t)v);
+				emitted++;
+				sp--;
+				if (sp > 0) l.wrb(LY::X_ORD, LY::OB_STCUR + sp - 1, l.rdb(LY::X_ORD, LY::OB_STCUR + sp - 1) + 1);
+			}
+		}
+	}
+	{ const uint64_t t2 = lap_clock(); st.blaps[4] += t2 - bt; bt = t2; }
 	return GA_OK;
 }
 
@@ -841,6 +959,7 @@ template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m
 	st.nRows = 0; st.numSlices = 0; st.seedNode = 0; st.eq = L.eq;
 	st.logCorrect = 0; st.logWrong = 0;
 	for (int i = 0; i < 8; i++) st.laps[i] = 0;
+	for (int i = 0; i < 5; i++) st.blaps[i] = 0;
 	if (!hasJob) return;
 	const GaJob job = L.jobs[jobIndex];
 	st.nRows = job.n_rows;
