@@ -78,7 +78,7 @@ template <int N, int LW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) ga_lanes_kernel(gal::GaLanesLaunch L)
 {
 	using namespace gal;
-	__shared__ uint32_t lds[Lay<N>::WORDS * LW + 64 * kStageWords64 * 2];
+	__shared__ uint32_t lds[Lay<N>::WORDS * LW + LW * kStageWords64 * 2];      // tables, then the staging image of LW lanes
 	const int lane = (int)threadIdx.x;
 	const WaveLayout lay = wave_layout<N>(L.cap_cols, L.cap_rows, L.max_slices, L.cap_moves);
 	uint8_t* base = L.scratch + (uint64_t)blockIdx.x * L.wave_bytes;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 			lane_band<N>(L, m, st, slice);
 			GAL_LAP(0);
 			if (!__ballot(st.live)) break;
-			fill_slice<N, 8>(L.graph, m, st, slice, st.live, rowTop, L.cap_rows, L.cap_cols);
+			fill_slice<N, 8, LW>(L.graph, m, st, slice, st.live, rowTop, L.cap_rows, L.cap_cols);
 			GAL_LAP(1);
 			lane_end_slice<N>(L, m, st, slice);
 			GAL_LAP(2);
@@ -358,11 +358,18 @@ struct DevBatch : GaBackendBatch
 		P.cap_moves = maxRows * 2 + 1024;
 		const gal::WaveLayout lay = gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves);
 		P.wave_bytes = lay.bytes;
-		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + 64 * gal::kStageWords64 * 8;
+		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + LW * gal::kStageWords64 * 8;
 		const uint32_t wavesPerCu = std::max<uint32_t>(1, std::min<uint32_t>(8, 163840u / ldsBytes));
-		const uint64_t groups = (list.size() + LW - 1) / LW;
 		const uint64_t fit = scratchBudget() / std::max<uint64_t>(lay.bytes, 1);
-		const uint32_t waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * wavesPerCu, fit), groups));
+		const uint64_t slotsHere = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g->cus * wavesPerCu, fit));
+		// a batch that does not fill every wave slot with LW jobs is spread over all of them: a wave's steps cost the same with
+		// fewer lanes, and fewer lanes wait for each other less (GA_LANES_SPREAD=0: full waves)
+		uint32_t lanesPer = LW;
+		if (!(getenv("GA_LANES_SPREAD") && atoi(getenv("GA_LANES_SPREAD")) == 0) && list.size() < slotsHere * LW)
+			lanesPer = (uint32_t)std::min<uint64_t>(LW, std::max<uint64_t>(8, (list.size() + slotsHere - 1) / slotsHere));
+		P.lanes_per_wave = lanesPer;
+		const uint64_t groups = (list.size() + lanesPer - 1) / lanesPer;
+		const uint32_t waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(slotsHere, groups));
 		bool fromPool = false;
 		uint8_t* scratch = takeScratch((size_t)waves * lay.bytes, fromPool);
 		if (!scratch) return 0;                            // no memory for this variant: the jobs keep their status and climb on

@@ -654,12 +654,13 @@ template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c
 #ifndef GA_EMULATE
 // the wave's 8 x 64 records of arena block `block` leave as twelve coalesced 1 KB stores: 16-byte chunk q of the 12 KB block
 // belongs to lane q / 12 (rec_off<8>: lane-major inside a block)
-GAL_FN void stage_flush(const LaneMem& m, uint32_t block)
+template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t block)
 {
 	__builtin_amdgcn_wave_barrier();
 	uint8_t* dst = m.arena + (uint64_t)block * (64 * 8 * kRecBytes);
+	// (a kernel whose waves carry LW < 64 jobs stages, and writes back, only those lanes' part of the block)
 #pragma unroll
-	for (int j = 0; j < 12; j++)
+	for (int j = 0; j < 12 * LW / 64; j++)
 	{
 		const uint32_t q = (uint32_t)m.lane + 64u * (uint32_t)j;
 		const uint32_t ln = q / 12u, part = q % 12u;
@@ -707,7 +708,7 @@ GAL_FN uint32_t wave_max(uint32_t v)
 GAL_FN uint32_t wave_max(uint32_t v) { return v; }
 #endif
 
-template <int N, int U>
+template <int N, int U, int LW = 64>
 GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uint32_t slice, bool active, uint32_t& rowTop, uint32_t capRows, uint32_t capCols)
 {
 	typedef Lay<N> LY;
@@ -918,7 +919,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 				emit(on, w, i);
 			}
 #ifndef GA_EMULATE
-			stage_flush(m, (t0 >> 3) + j);                                       // the chunk's block of U rows is complete
+			stage_flush<LW>(m, (t0 >> 3) + j);                                       // the chunk's block of U rows is complete
 #endif
 #pragma unroll
 			for (int i = 0; i < U; i++) pe[i] = pe2[i];

@@ -31,4 +31,22 @@ if 'WRITE_SIZE' in out: out['hbm_write_bytes'] = out['WRITE_SIZE'] * 1024
 out['per_column_update'] = {k: round(v / cols, 3) for k, v in out.items() if k.startswith('SQ_') or k.startswith('TCC')}
 json.dump(out, open('$O/summary.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
+# the HBM traffic per column update that bench.py scales to its own launch (-> profiles/r2_hbm_traffic.json)
+if 'FETCH_SIZE' in out and 'WRITE_SIZE' in out:
+    rd, wr = out['FETCH_SIZE'] * 1024, out['WRITE_SIZE'] * 1024
+    t = {
+     "command": "bash tools/pmc_lanes.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of: python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0)",
+     "kernel": b['roofline']['kernel'],
+     "build": "$(git rev-parse --short HEAD 2>/dev/null || echo round-2-final)",
+     "column_updates_per_launch": cols,
+     "FETCH_SIZE_KB": out['FETCH_SIZE'], "WRITE_SIZE_KB": out['WRITE_SIZE'],
+     "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM); this kernel's reads are 4-24 B per lane, which that guide calls uncalibrated; the x2 figure is used as the conservative one",
+     "hbm_read_bytes_uncorrected": rd, "hbm_read_bytes_x2": 2 * rd, "hbm_write_bytes": wr,
+     "hbm_bytes_per_column_update": (2 * rd + wr) / cols,
+     "hbm_bytes_per_column_update_uncorrected": (rd + wr) / cols,
+     "algorithmic_bytes_per_column_update": 28.0,
+     "kernel_ms_under_counters": b['roofline']['kernel_ms'],
+     "note": "writes above the 24 + 4 B algorithmic figure: the arena is written one 1.5 KB row per step of the WAVE (all 64 lanes' slots, also those of lanes whose node is shorter, whose band has fewer nodes, or that carry no job when a batch is spread over all wave slots), plus per-slice headers and node lists; reads: the traceback's column windows (24 B records in 192 B blocks), previous end words, graph records"
+    }
+    json.dump(t, open('$O/hbm_traffic.json', 'w'), indent=1)
 PY
