@@ -246,6 +246,10 @@ def main():
         names = ["end_slice", "band+order", "trace_fast(in traceback)", "trace_general(in traceback)", "fill", "traceback", "trace_handover(in traceback)", "rounds|fast_iterations<<32"]
         if os.environ.get("GA_STAMPS_LEVEL") == "2":      # the traceback's general step in parts instead of the slice phases
             names[0], names[1], names[4] = "general:decide", "general:slice_change", "general:window"
+        if os.environ.get("GA_STAMPS_LEVEL") == "4":      # the band phase in parts; [6] = the band phase, [7] = the fill
+            names = ["band:map_order", "band:previous_band", "band:heap", "band:slots", "band:processing_order", "traceback", "band phase", "fill"]
+        if os.environ.get("GA_STAMPS_LEVEL") in ("3", "4"):
+            tot = float(st["stamps"][5] + st["stamps"][6] + st["stamps"][7]) or 1.0
 
         tot = float(st["stamps"][0] + st["stamps"][1] + st["stamps"][4] + st["stamps"][5]) or 1.0
         out["detail"]["phase_share"] = {n: round(v / tot, 4) for n, v in zip(names, st["stamps"])}

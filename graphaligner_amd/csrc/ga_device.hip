@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 		m.lds.base = lds + (lane < LW ? lane : 0);
 		m.lds.lw = LW;
 		m.stage = (uint64_t*)(lds + Lay<N>::WORDS * LW);
+		m.usedChunks = 12u * (L.lanes_per_wave < (uint32_t)LW ? L.lanes_per_wave : (uint32_t)LW);
 		m.endPrev = (uint32_t*)(base + lay.endA) + lane;
 		m.endCur = (uint32_t*)(base + lay.endB) + lane;
 		m.hdr = (uint32_t*)(base + lay.hdr) + lane;
@@ -354,7 +355,7 @@ struct DevBatch : GaBackendBatch
 		for (uint32_t i : list) maxRows = std::max(maxRows, jobs[i].n_rows);
 		P.max_slices = std::max<uint32_t>(maxRows / 64, 1);
 		P.cap_cols = std::min<uint32_t>(N * 256u, 0xff00u);
-		P.cap_rows = P.max_slices * rowsPerSlice + 64;
+		P.cap_rows = (P.max_slices * rowsPerSlice + 64 + 7u) & ~7u;               // (whole blocks of 8 rows: the block behind them is the spare one)
 		P.cap_moves = maxRows * 2 + 1024;
 		const gal::WaveLayout lay = gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves);
 		P.wave_bytes = lay.bytes;
@@ -390,7 +391,7 @@ struct DevBatch : GaBackendBatch
 				for (auto& o : outs) if (o.stamps[1]) { lo = std::min(lo, o.stamps[0]); hi = std::max(hi, o.stamps[1]); }
 				for (auto& o : outs) if (o.stamps[1]) { n++; life += (double)(o.stamps[1] - o.stamps[0]); cyc += (double)o.stamps[4]; lateStart = std::max(lateStart, (double)(o.stamps[0] - lo)); }
 				if (n) fprintf(stderr, "graphaligner_amd: %llu waves: first start to last end %.3f ms, mean wave life %.3f ms = %.1f M shader cycles (%.2f GHz), latest start %.3f ms after the first\n",
-				               (unsigned long long)n, (hi - lo) / 1e5, life / n / 1e5, cyc / n / 1e6, cyc / life / 1e4, lateStart / 1e5);
+				               (unsigned long long)n, (hi - lo) / 1e5, life / n / 1e5, cyc / n / 1e6, cyc / life / 10.0, lateStart / 1e5);
 			}
 #endif
 		}

@@ -159,6 +159,7 @@ struct LaneMem
 	uint32_t* moves;
 	uint8_t* arena;
 	uint64_t* stage;              // device: the wave's LDS image of the open block of 8 arena rows
+	uint32_t usedChunks;          // device: 16-byte chunks of a block image that belong to lanes with a job (12 per lane)
 	int lane;
 };
 
@@ -654,10 +655,13 @@ template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c
 #ifndef GA_EMULATE
 // the wave's 8 x 64 records of arena block `block` leave as twelve coalesced 1 KB stores: 16-byte chunk q of the 12 KB block
 // belongs to lane q / 12 (rec_off<8>: lane-major inside a block)
-template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t block)
+template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t block, uint32_t spareBlock)
 {
 	__builtin_amdgcn_wave_barrier();
 	uint8_t* dst = m.arena + (uint64_t)block * (64 * 8 * kRecBytes);
+	// the part of lanes that carry no job (a batch spread over more waves than it fills) goes to a spare block behind the arena's
+	// rows instead: the same few lines over and over, which the L2 absorbs -- the stores stay unconditional, HBM sees the used part
+	uint8_t* spare = m.arena + (uint64_t)spareBlock * (64 * 8 * kRecBytes);
 	// (a kernel whose waves carry LW < 64 jobs stages, and writes back, only those lanes' part of the block)
 #pragma unroll
 	for (int j = 0; j < 12 * LW / 64; j++)
@@ -666,7 +670,7 @@ template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t block)
 		const uint32_t ln = q / 12u, part = q % 12u;
 		const uint64_t* sp = m.stage + ln * 25 + part * 2;
 		const uint64_t a = sp[0], b = sp[1];
-		uint64_t* d = (uint64_t*)(dst + (uint64_t)q * 16);
+		uint64_t* d = (uint64_t*)((q < m.usedChunks ? dst : spare) + (uint64_t)q * 16);
 		d[0] = a; d[1] = b;
 	}
 	__builtin_amdgcn_wave_barrier();
@@ -919,7 +923,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 				emit(on, w, i);
 			}
 #ifndef GA_EMULATE
-			stage_flush<LW>(m, (t0 >> 3) + j);                                       // the chunk's block of U rows is complete
+			stage_flush<LW>(m, (t0 >> 3) + j, capRows >> 3);                                       // the chunk's block of U rows is complete
 #endif
 #pragma unroll
 			for (int i = 0; i < U; i++) pe[i] = pe2[i];
