@@ -12,6 +12,7 @@
 #include <limits>
 #include <sstream>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <tuple>
 #include <unordered_map>
@@ -798,16 +799,46 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		return t;
 	};
 
-	auto work = [&](size_t lo, size_t hi, ResultsOwner* R) {
+	// Every read's results go straight into the batch's arrays, at places fixed before the threads start: a read's path has at most
+	// (moves that left a node through its first column, counted by the traceback) + 1 node runs per job, its edit sequences are pieces
+	// of the read, its trace items at most one per move.  The arrays have gaps where a read needs less; first_mapping / n_mappings,
+	// edit_seq_off and first_trace / n_trace say where each read's entries are.
+	const size_t nReadsAll = b->reads.size();
+	const bool wantTraceAll = (b->flags & GA_F_TRACE) != 0;
+	std::vector<uint64_t> mapAt(nReadsAll + 1, 0), editAt(nReadsAll + 1, 0), traceAt(nReadsAll + 1, 0);
+	for (size_t ri = 0; ri < nReadsAll; ri++)
+	{
+		const ReadPlan& rp = b->reads[ri];
+		uint64_t runs = 1, items = 0;
+		for (size_t k = rp.firstSeed; k < rp.firstSeed + rp.nSeeds; k++)
+			for (int64_t job : {b->seeds[k].bwJob, b->seeds[k].fwJob})
+				if (job >= 0 && outs[job].status == GA_OK) { runs += (uint64_t)outs[job].n_node_steps + 1; items += (uint64_t)outs[job].trace_len + 2; }
+		mapAt[ri + 1] = mapAt[ri] + runs;
+		editAt[ri + 1] = editAt[ri] + b->seqs[ri].size() + 8;
+		traceAt[ri + 1] = traceAt[ri] + (wantTraceAll ? items : 0);
+	}
+	R->allReads.reset(new ga_read_result_t[nReadsAll + 1]);
+	R->allMappings.reset(new ga_mapping_t[mapAt[nReadsAll] + 1]);
+	R->allEdits.reset(new char[editAt[nReadsAll] + 1]);
+	R->allTrace.reset(new ga_trace_item_t[traceAt[nReadsAll] + 1]);
+	ga_read_result_t* const allReads = R->allReads.get();
+	ga_mapping_t* const allMappings = R->allMappings.get();
+	char* const allEdits = R->allEdits.get();
+	ga_trace_item_t* const allTrace = R->allTrace.get();
+	std::atomic<int> overflow{0};
+	std::atomic<uint64_t> columnUpdatesAll{0};
+
+	auto work = [&](size_t lo, size_t hi) {
+	std::vector<ga_trace_item_t> items;
+	uint64_t columnUpdates = 0;
 	for (size_t ri = lo; ri < hi; ri++)
 	{
-		R->reads.emplace_back();
-		ga_read_result_t& rr = R->reads.back();
+		ga_read_result_t& rr = allReads[ri];
 		memset(&rr, 0, sizeof(rr));
 		rr.failed = 1;
 		rr.score = kMax;
-		rr.first_mapping = R->mappings.size();
-		rr.first_trace = R->trace.size();
+		rr.first_mapping = mapAt[ri];
+		rr.first_trace = traceAt[ri];
 		const std::string& seq = b->seqs[ri];
 		const ReadPlan& rp = b->reads[ri];
 		if (rp.nSeeds == 0) { rr.status = GA_S_ASSERTION; continue; }          // assert(seedHits.size() > 0) (:412)
@@ -875,110 +906,87 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 			}
 		}
 		rr.status = status;
+		columnUpdates += rr.column_updates;
 		if (status != GA_S_OK || !have) continue;
-		size_t traceMark = R->trace.size();
 		// the reference always builds the TraceItem list (:463) and characterMatch asserts on a
 		// non-IUPAC read character; only reads that contain one need the scan when no trace is wanted
-		bool wantTrace = (b->flags & GA_F_TRACE) != 0;
+		bool wantTrace = wantTraceAll;
 		bool suspicious = false;
 		if (!wantTrace) for (char c : seq) if (tables().rowCode[(uint8_t)c] & GA_ROW_INVALID) { suspicious = true; break; }
+		items.clear();
 		if (wantTrace || suspicious)
 		{
-			bool fine = traceItems(g, seq, bestBw, bestFw, R->trace);
-			if (!wantTrace || !fine) R->trace.resize(traceMark);
+			bool fine = traceItems(g, seq, bestBw, bestFw, items);
+			if (!wantTrace || !fine) items.clear();
 			if (!fine) { rr.status = GA_S_ASSERTION; continue; }
 		}
 		Partial fwp = toMappings(g, seq, bestFwScore, bestFw);
 		Partial bwp = toMappings(g, seq, bestBwScore, bestBw);
-		if (fwp.failed && bwp.failed) { R->trace.resize(traceMark); continue; }
+		if (fwp.failed && bwp.failed) continue;
 		Partial merged = mergePartials(g, bwp, fwp);
+		uint64_t editBytes = 0;
+		for (const std::string& piece : merged.seqs) editBytes += piece.size();
+		if (merged.maps.size() > mapAt[ri + 1] - mapAt[ri] || editBytes > editAt[ri + 1] - editAt[ri] || items.size() > traceAt[ri + 1] - traceAt[ri])
+		{
+			overflow.store(1);              // (a bound above is wrong: fail loudly instead of writing past a read's place)
+			rr.status = GA_E_DEVICE;
+			continue;
+		}
 		rr.failed = 0;
 		rr.score = merged.score;
 		rr.n_mappings = merged.maps.size();
+		uint64_t editTop = editAt[ri];
 		for (size_t i = 0; i < merged.maps.size(); i++)
 		{
 			ga_mapping_t m = merged.maps[i];
-			m.edit_seq_off = R->edits.size();
-			R->edits.insert(R->edits.end(), merged.seqs[i].begin(), merged.seqs[i].end());
-			R->mappings.push_back(m);
+			m.edit_seq_off = editTop;
+			memcpy(allEdits + editTop, merged.seqs[i].data(), merged.seqs[i].size());
+			editTop += merged.seqs[i].size();
+			allMappings[mapAt[ri] + i] = m;
 		}
-		rr.n_trace = R->trace.size() - traceMark;
+		rr.n_trace = items.size();
+		if (!items.empty()) memcpy(allTrace + traceAt[ri], items.data(), items.size() * sizeof(items[0]));
 		uint64_t lastAligned = !bestBw.empty() ? bestBw[0].row : bestPos;
 		rr.query_position = lastAligned;
 		rr.alignment_start = lastAligned;
 		rr.alignment_end = lastAligned + bestEstimate;
 	}
+	columnUpdatesAll += columnUpdates;
 	};
-	// reads are independent: assemble them on several host threads, then stitch the per-thread arrays
+	// reads are independent: assembled on several host threads
 	size_t nThreads = std::thread::hardware_concurrency();
 	if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
-	nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), b->reads.size() / 64 + 1));
-	std::vector<ResultsOwner> parts(nThreads);
+	nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), nReadsAll / 64 + 1));
 	{
-		std::vector<std::thread> pool;
-		size_t per = (b->reads.size() + nThreads - 1) / nThreads;
-		for (size_t t = 0; t < nThreads; t++)
-		{
-			size_t lo = std::min(b->reads.size(), t * per), hi = std::min(b->reads.size(), lo + per);
-			pool.emplace_back(work, lo, hi, &parts[t]);
-		}
-		for (auto& th : pool) th.join();
-	}
-	for (const ResultsOwner& part : parts) for (const ga_read_result_t& rr : part.reads) b->columnUpdates += rr.column_updates;
-	b->dev->fetchDone();
-	const auto t2 = std::chrono::steady_clock::now();
-	// stitch the per-thread arrays: sizes first, then every part copies itself into place (rebased offsets) on its own thread
-	{
-		std::vector<uint64_t> readBase(nThreads + 1, 0), mapBase(nThreads + 1, 0), editBase(nThreads + 1, 0), traceBase(nThreads + 1, 0);
-		for (size_t t = 0; t < nThreads; t++)
-		{
-			readBase[t + 1] = readBase[t] + parts[t].reads.size();
-			mapBase[t + 1] = mapBase[t] + parts[t].mappings.size();
-			editBase[t + 1] = editBase[t] + parts[t].edits.size();
-			traceBase[t + 1] = traceBase[t] + parts[t].trace.size();
-		}
-		R->allReads.reset(new ga_read_result_t[readBase[nThreads] + 1]);
-		R->allMappings.reset(new ga_mapping_t[mapBase[nThreads] + 1]);
-		R->allEdits.reset(new char[editBase[nThreads] + 1]);
-		R->allTrace.reset(new ga_trace_item_t[traceBase[nThreads] + 1]);
-		ga_read_result_t* const allReads = R->allReads.get();
-		ga_mapping_t* const allMappings = R->allMappings.get();
-		char* const allEdits = R->allEdits.get();
-		ga_trace_item_t* const allTrace = R->allTrace.get();
-		R->pub.n_reads = readBase[nThreads]; R->pub.reads = allReads;
-		R->pub.n_mappings = mapBase[nThreads]; R->pub.mappings = allMappings;
-		R->pub.n_edit_bytes = editBase[nThreads]; R->pub.edit_bytes = allEdits;
-		R->pub.n_trace = traceBase[nThreads]; R->pub.trace = allTrace;
+		// (small pieces handed out from a counter: reads sorted by nothing in particular, but their lengths differ)
+		std::atomic<size_t> next{0};
+		const size_t piece = std::max<size_t>(16, nReadsAll / (nThreads * 16) + 1);
 		std::vector<std::thread> pool;
 		for (size_t t = 0; t < nThreads; t++)
-			pool.emplace_back([&, t]() {
-				ResultsOwner& part = parts[t];
-				for (size_t i = 0; i < part.reads.size(); i++)
+			pool.emplace_back([&]() {
+				while (true)
 				{
-					ga_read_result_t rr = part.reads[i];
-					rr.first_mapping += mapBase[t];
-					rr.first_trace += traceBase[t];
-					allReads[readBase[t] + i] = rr;
+					const size_t lo = next.fetch_add(piece);
+					if (lo >= nReadsAll) break;
+					work(lo, std::min(nReadsAll, lo + piece));
 				}
-				for (size_t i = 0; i < part.mappings.size(); i++)
-				{
-					ga_mapping_t m = part.mappings[i];
-					m.edit_seq_off += editBase[t];
-					allMappings[mapBase[t] + i] = m;
-				}
-				if (!part.edits.empty()) memcpy(allEdits + editBase[t], part.edits.data(), part.edits.size() * sizeof(part.edits[0]));
-				if (!part.trace.empty()) memcpy(allTrace + traceBase[t], part.trace.data(), part.trace.size() * sizeof(part.trace[0]));
-
-				std::vector<ga_mapping_t>().swap(part.mappings);
 			});
 		for (auto& th : pool) th.join();
 	}
+	b->columnUpdates += columnUpdatesAll.load();
+	b->dev->fetchDone();
+	const auto t2 = std::chrono::steady_clock::now();
+	if (overflow.load()) { delete R; return GA_E_DEVICE; }
+	R->pub.n_reads = nReadsAll; R->pub.reads = allReads;
+	R->pub.n_mappings = mapAt[nReadsAll]; R->pub.mappings = allMappings;
+	R->pub.n_edit_bytes = editAt[nReadsAll]; R->pub.edit_bytes = allEdits;
+	R->pub.n_trace = traceAt[nReadsAll]; R->pub.trace = allTrace;
 	*out = &R->pub;
 	if (getenv("GA_DEBUG_COLLECT"))
 	{
 		const auto t3 = std::chrono::steady_clock::now();
 		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-		fprintf(stderr, "graphaligner_amd: collect: fetch %.1f ms (%zu trace bytes), assembly %.1f ms on %zu threads, stitch %.1f ms\n", ms(t0, t1), (size_t)nMoveBytes, ms(t1, t2), nThreads, ms(t2, t3));
+		fprintf(stderr, "graphaligner_amd: collect: fetch %.1f ms (%zu trace bytes), assembly %.1f ms on %zu threads, hand-over %.1f ms\n", ms(t0, t1), (size_t)nMoveBytes, ms(t1, t2), nThreads, ms(t2, t3));
 	}
 	return GA_S_OK;
 }

@@ -1363,7 +1363,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	Slot slot = slotIn;
 	GaJobOut out;
 	out.status = GA_OK; out.score = 0x7fffffff; out.n_valid = 0; out.n_run = 0; out.trace_len = 0; out.max_band_nodes = 0; out.n_columns = 0; out.trace_off = 0;
-	out.start_node = 0; out.start_offset = 0; out.start_row = 0; out.reserved2 = 0;
+	out.start_node = 0; out.start_offset = 0; out.start_row = 0; out.reserved2 = 0; out.n_node_steps = 0; out.reserved3 = 0;
 	for (int i = 0; i < 8; i++) out.stamps[i] = 0;
 	uint64_t tA = stamp(), tB;
 #define GA_LAP(i) do { tB = stamp(); out.stamps[i] += tB - tA; tA = tB; } while (0)
@@ -1636,14 +1636,12 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	uint32_t startRec = kept > 0 ? slot.slice_off[kept - 1] : 0;
 	if constexpr (kWide)
 	{
-		if (status == GA_OK && redone && kept > 0 && numSlices >= 4)
+		if (status == GA_OK && redone)
 		{
+			// the checks at the end of getSqrtSlices (:2833-2842) look at the whole checkpoint list, before the wrongly aligned tail
+			// is trimmed (removeWronglyAlignedEnd is the caller's next step, :3002,3018) and whether or not anything is kept
 			wave_sync();
-			const auto firstPassColumns = out.n_columns;                          // the column-update count is the first pass's (cellsProcessed)
-			const auto firstPassNodes = out.max_band_nodes;
 			if (nCkpt == 0) status = GA_ASSERTION;                                // :2834
-			// trimmed checkpoints (:2566-2568)
-			while (status == GA_OK && nCkpt > 1 && slot.ckpt[nCkpt - 1] != kSeedRecord && recSlice(slot.ckpt[nCkpt - 1]) >= kept) nCkpt--;
 			for (uint32_t i = 1; i < nCkpt && status == GA_OK; i++)
 			{
 				const uint32_t a = slot.ckpt[i - 1], b = slot.ckpt[i];
@@ -1651,6 +1649,15 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				const int ma = a == kSeedRecord ? 0 : (int)slot.arena[a + 2], mb = b == kSeedRecord ? 0 : (int)slot.arena[b + 2];
 				if (mb < ma) status = GA_ASSERTION;                                                // :2839-2842
 			}
+			if (status != GA_OK) out.n_valid = 0;
+		}
+		if (status == GA_OK && redone && kept > 0 && numSlices >= 4)
+		{
+			wave_sync();
+			const auto firstPassColumns = out.n_columns;                          // the column-update count is the first pass's (cellsProcessed)
+			const auto firstPassNodes = out.max_band_nodes;
+			// trimmed checkpoints (:2566-2568)
+			while (status == GA_OK && nCkpt > 1 && slot.ckpt[nCkpt - 1] != kSeedRecord && recSlice(slot.ckpt[nCkpt - 1]) >= kept) nCkpt--;
 			for (uint32_t sIdx = 0; sIdx < kept; sIdx++) if (GA_LANE0) slot.below_off[sIdx] = slot.slice_off[sIdx];
 			wave_sync();
 			for (uint32_t i = nCkpt; i-- > 0 && status == GA_OK;)
@@ -1710,7 +1717,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		uint32_t node = from.nodes[from.hdr[3]];
 		uint32_t offset = from.hdr[4];
 		uint32_t row = sIdx * W + (W - 1);
-		uint32_t len = 0;
+		uint32_t len = 0, nodeSteps = 0;
 		out.start_node = node; out.start_offset = offset; out.start_row = row;
 		SliceRec prv = cur;
 		uint32_t pN = 0;
@@ -1938,6 +1945,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				}
 			}
 			else res = decide(read_lane(valR, rel - 1), read_lane(valUp, rel - 1), curNode, curOffset - 1);
+			if (curOffset == 0 && (res == 1 || res == 2)) nodeSteps++;           // left the node through its first column
 			if (res < 0) { status = GA_ASSERTION; break; }
 			if (res == 0)
 			{
@@ -1991,6 +1999,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				for (uint32_t c = 0; c < words; c += LANES) store_lanes(dst + c, (int)(words - c), load_lanes(src + c, (int)(words - c), 0));
 				out.trace_off = at;
 				out.trace_len = len;
+				out.n_node_steps = nodeSteps;
 			}
 		}
 	}

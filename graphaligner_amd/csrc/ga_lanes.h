@@ -1067,6 +1067,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 	GaJobOut out;
 	out.status = st.status; out.score = 0x7fffffff; out.n_valid = 0; out.n_run = st.nRun; out.trace_len = 0; out.max_band_nodes = st.maxBandNodes;
 	out.n_columns = st.nColumns; out.trace_off = 0; out.start_node = 0; out.start_offset = 0; out.start_row = 0; out.reserved2 = 0;
+	out.n_node_steps = 0; out.reserved3 = 0;
 	for (int i = 0; i < 8; i++) out.stamps[i] = 0;
 	int status = st.status;
 	// ---- drop the wrongly aligned tail (removeWronglyAlignedEnd, :2554-2569) ----
@@ -1082,7 +1083,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		}
 	}
 	out.n_valid = status == GA_OK ? kept : 0;
-	uint32_t len = 0;
+	uint32_t len = 0, nodeSteps = 0;
 	if (status == GA_OK && kept > 0)
 	{
 		const int big = (int)st.nRows;                                            // getValueOrMax default = sequence.size()
@@ -1420,7 +1421,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 							res = decide(horizontal, diagonal, nb[k], mo);
 						}
 					}
-					if (res == 1 || res == 2) needSetup = true;                        // entered another node
+					if (res == 1 || res == 2) { needSetup = true; nodeSteps++; }       // entered another node
 				}
 				else
 				{
@@ -1572,6 +1573,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				}
 				out.trace_off = at;
 				out.trace_len = len;
+				out.n_node_steps = nodeSteps;
 			}
 		}
 	}

@@ -60,6 +60,8 @@ struct GaJobOut {
 	uint64_t n_columns;    // column updates = sum over computed slices of band columns
 	uint64_t trace_off;    // byte offset of this job's moves inside the trace pool
 	uint32_t start_node, start_offset, start_row, reserved2;   // where the traceback starts (last kept slice, last row)
+	uint32_t n_node_steps;  // moves that left a node through its first column: the path has at most this many + 1 node runs
+	uint32_t reserved3;
 	uint64_t stamps[8];    // diagnostic builds only (GA_STAMPS): shader cycles per phase; zero otherwise
 };
 
