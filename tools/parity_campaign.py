@@ -13,13 +13,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def main(argv=None, quiet=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=60)
     ap.add_argument("--reads", type=int, default=24)
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--emul", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--only", type=int, nargs="*", default=None, help="align only these trials (the others are still generated, so the random stream is the same)")
+    args = ap.parse_args(argv)
     import numpy as np
     from graphaligner_amd import synth
     import parity_common as pc
@@ -62,6 +63,8 @@ def main():
             for _ in range(8):
                 b[int(rng.integers(len(b)))] = ord("NRYKMSWBDVnacgt"[int(rng.integers(15))])
             reads[k] = b.decode()
+        if args.only is not None and trial not in args.only:
+            continue
         devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, ramp=ramp, lib_path=lib)
         for i, (d, o) in enumerate(zip(devs, oras)):
             stats["reads"] += 1
@@ -76,6 +79,8 @@ def main():
                 if len(stats["first_mismatches"]) < 5:
                     stats["first_mismatches"].append(dict(trial=trial, node_len=nl, snp=snp, indel=indel, sv=sv, L=L, bw=bw, err=err, mid=mid, what=str(e)[:300]))
     stats["seconds"] = round(time.time() - t0, 1)
+    if quiet:
+        return stats
     print(json.dumps(stats))
     return 1 if stats["mismatches"] else 0
 
