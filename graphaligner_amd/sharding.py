@@ -58,11 +58,12 @@ class _Counter:
         return int(self.store.add(self.key, 1)) - 1
 
 
-def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chunk_reads=65536, tag="ga_queue"):
+def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chunk_reads=65536, tag="ga_queue", summary=False):
     """every rank calls this with the SAME reads/seeds and its own `graph` (already uploaded to its GPU).  Chunks of reads are pulled
     from a shared counter, so a rank that finishes early takes more; on each rank three stages overlap on separate host threads and
     HIP streams: job building + upload of chunk k+1, the kernels of chunk k, download + assembly of chunk k-1.  Rank 0 gets the full
-    result list in input order, other ranks get None.  No collective on the data path."""
+    result list in input order, other ranks get None.  No collective on the data path.  summary=True: per-read numpy records
+    (Batch.collect(summary=True)) instead of Python lists, for callers that only count or that read the arrays themselves."""
     from concurrent.futures import ThreadPoolExecutor
     chunks = make_chunks([len(r) for r in reads], chunk_reads)
     counter = _Counter(dist, tag)
@@ -85,7 +86,7 @@ def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chu
             k2 = take()
             nxt = pool.submit(prep, k2) if k2 is not None else None      # built and uploaded while chunk k runs
             batch.run()
-            done.append((k, pool.submit(batch.collect)))                 # assembled while the next chunk runs
+            done.append((k, pool.submit(batch.collect, summary)))        # assembled while the next chunk runs
         mine = [(k, f.result()) for k, f in done]
     if multi:
         gathered = [None] * dist.get_world_size()
@@ -93,6 +94,11 @@ def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chu
         if dist.get_rank() != 0:
             return None
         mine = [kr for part in gathered for kr in part]
+    if summary:
+        out = np.zeros(len(reads), dtype=mine[0][1].dtype) if mine else np.zeros(0)
+        for k, res in mine:
+            out[np.asarray(chunks[k], dtype=np.int64)] = res
+        return out
     out = [None] * len(reads)
     for k, res in mine:
         for i, r in zip(chunks[k], res):
