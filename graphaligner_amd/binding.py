@@ -153,7 +153,7 @@ class Graph:
         return self.L.ga_graph_bp(self.h)
 
     def prepare(self, reads, seeds, bw, ramp=0, flags=0, names=None):
-        """reads: list of str; seeds: list (one entry per read) of lists of (node, pos, reverse) or a single tuple"""
+        """reads: list of str (or a ReadSet, then seeds is ignored); seeds: list (one entry per read) of lists of (node, pos, reverse) or a single tuple"""
         return Batch(self, reads, seeds, bw, ramp, flags, names)
 
     def align(self, reads, seeds, bw, ramp=0, flags=0):
@@ -162,10 +162,11 @@ class Graph:
         return b.collect()
 
 
-class Batch:
-    def __init__(self, graph, reads, seeds, bw, ramp, flags, names=None):
-        self.g = graph
-        L = self.L = graph.L
+class ReadSet:
+    """reads and seeds in the form the C ABI takes them (arrays of ga_read_t / ga_seed_t + CSR offsets): what an application that
+    calls the library from C or C++ already holds.  Built once, it can be handed to Graph.prepare any number of times."""
+
+    def __init__(self, reads, seeds, names=None):
         n = len(reads)
         self._keep = [r.encode() if isinstance(r, str) else r for r in reads]
         arr = (GaRead * max(n, 1))()
@@ -185,11 +186,22 @@ class Batch:
             sarr[i].node_id = int(node)
             sarr[i].read_pos = int(pos)
             sarr[i].reverse = int(bool(rev))
-        self._arr, self._sarr, self._offs = arr, sarr, offs
+        self.arr, self.sarr, self.offs = arr, sarr, offs
         self.n_reads = n
         self.total_bp = sum(len(r) for r in self._keep)
+
+
+class Batch:
+    def __init__(self, graph, reads, seeds, bw, ramp, flags, names=None):
+        self.g = graph
+        L = self.L = graph.L
+        rs = reads if isinstance(reads, ReadSet) else ReadSet(reads, seeds, names)
+        self._rs = rs                      # (the arrays must outlive the batch: GAM encoding reads the names)
+        self._arr, self._sarr, self._offs = rs.arr, rs.sarr, rs.offs
+        self.n_reads = rs.n_reads
+        self.total_bp = rs.total_bp
         h = C.c_void_p()
-        _check(L, L.ga_batch_prepare(graph.h, arr, n, sarr, offs.ctypes.data_as(C.c_void_p), bw, ramp, flags, C.byref(h)), "ga_batch_prepare")
+        _check(L, L.ga_batch_prepare(graph.h, rs.arr, rs.n_reads, rs.sarr, rs.offs.ctypes.data_as(C.c_void_p), bw, ramp, flags, C.byref(h)), "ga_batch_prepare")
         self.h = h
 
     def run(self):

@@ -58,36 +58,54 @@ class _Counter:
         return int(self.store.add(self.key, 1)) - 1
 
 
+def run_overlapped(graph, inputs, bandwidth, ramp=0, flags=0, summary=False):
+    """`inputs` yields (key, (reads, seeds)) or (key, binding.ReadSet); three stages overlap on separate host threads and HIP streams:
+    job building + upload of input k+1, the kernels of input k, download + assembly of input k-1.  Returns [(key, results)]."""
+    from concurrent.futures import ThreadPoolExecutor
+    it = iter(inputs)
+
+    def prep():
+        try:
+            key, what = next(it)
+        except StopIteration:
+            return None
+        if isinstance(what, tuple):
+            return key, graph.prepare(what[0], what[1], bandwidth, ramp, flags)
+        return key, graph.prepare(what, None, bandwidth, ramp, flags)
+
+    done = []                         # (key, future of its results)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        nxt = pool.submit(prep)
+        while True:
+            got = nxt.result()
+            if got is None:
+                break
+            key, batch = got
+            nxt = pool.submit(prep)                                      # built and uploaded while this input runs
+            batch.run()
+            done.append((key, pool.submit(batch.collect, summary)))     # assembled while the next input runs
+        return [(k, f.result()) for k, f in done]
+
+
 def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chunk_reads=65536, tag="ga_queue", summary=False):
     """every rank calls this with the SAME reads/seeds and its own `graph` (already uploaded to its GPU).  Chunks of reads are pulled
-    from a shared counter, so a rank that finishes early takes more; on each rank three stages overlap on separate host threads and
-    HIP streams: job building + upload of chunk k+1, the kernels of chunk k, download + assembly of chunk k-1.  Rank 0 gets the full
-    result list in input order, other ranks get None.  No collective on the data path.  summary=True: per-read numpy records
-    (Batch.collect(summary=True)) instead of Python lists, for callers that only count or that read the arrays themselves."""
-    from concurrent.futures import ThreadPoolExecutor
+    from a shared counter, so a rank that finishes early takes more; on each rank the stages of consecutive chunks overlap
+    (run_overlapped).  Rank 0 gets the full result list in input order, other ranks get None.  No collective on the data path.
+    summary=True: per-read numpy records (Batch.collect(summary=True)) instead of Python lists, for callers that only count or that
+    read the arrays themselves."""
     chunks = make_chunks([len(r) for r in reads], chunk_reads)
     counter = _Counter(dist, tag)
     multi = counter.store is not None
 
-    def take():
-        k = counter.next()
-        return k if k < len(chunks) else None
+    def taken():
+        while True:
+            k = counter.next()
+            if k >= len(chunks):
+                return
+            idx = chunks[k]
+            yield k, ([reads[i] for i in idx], [seeds[i] for i in idx])
 
-    def prep(k):
-        idx = chunks[k]
-        return k, graph.prepare([reads[i] for i in idx], [seeds[i] for i in idx], bandwidth, ramp, flags)
-
-    done = []                         # (chunk number, future of its results)
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        k = take()
-        nxt = pool.submit(prep, k) if k is not None else None
-        while nxt is not None:
-            k, batch = nxt.result()
-            k2 = take()
-            nxt = pool.submit(prep, k2) if k2 is not None else None      # built and uploaded while chunk k runs
-            batch.run()
-            done.append((k, pool.submit(batch.collect, summary)))        # assembled while the next chunk runs
-        mine = [(k, f.result()) for k, f in done]
+    mine = run_overlapped(graph, taken(), bandwidth, ramp, flags, summary)
     if multi:
         gathered = [None] * dist.get_world_size()
         dist.all_gather_object(gathered, mine)
