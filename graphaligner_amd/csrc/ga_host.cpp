@@ -227,7 +227,9 @@ struct SeedPlan
 
 struct ReadPlan { size_t firstSeed = 0, nSeeds = 0; };
 
-struct Partial { bool failed = true; int32_t score = 0; std::vector<ga_mapping_t> maps; std::vector<std::string> seqs; };
+// (a mapping's edit sequence is a piece of the read: kept as a span of it, copied once into the results)
+struct SeqSpan { uint64_t pos, len; };
+struct Partial { bool failed = true; int32_t score = 0; std::vector<ga_mapping_t> maps; std::vector<SeqSpan> seqs; };
 
 }  // namespace
 
@@ -313,6 +315,13 @@ int mapDeviceStatus(int s)
 }
 
 // traceToAlignment (GraphAligner.h:782-847).  Node indices come straight from the device trace.
+// std::string::substr's clamping (the reference builds the pieces with substr, GraphAligner.h:829,845)
+static SeqSpan spanOf(const std::string& s, uint64_t pos, uint64_t len)
+{
+	if (pos > s.size()) pos = s.size();
+	return SeqSpan{pos, std::min<uint64_t>(len, s.size() - pos)};
+}
+
 Partial toMappings(const ga_graph& g, const std::string& sequence, int32_t score, const Trace& trace)
 {
 	Partial res;
@@ -342,7 +351,7 @@ Partial toMappings(const ga_graph& g, const std::string& sequence, int32_t score
 		m.from_length = (int64_t)(column(nodeEnd) - column(nodeStart) + 1);
 		m.to_length = (int64_t)(nodeEnd.row - beforeNode.row);
 		res.maps.push_back(m);
-		res.seqs.push_back(sequence.substr(nodeStart.row, nodeEnd.row - beforeNode.row));
+		res.seqs.push_back(spanOf(sequence, nodeStart.row, nodeEnd.row - beforeNode.row));
 		oldNode = trace[pos].node;
 		beforeNode = nodeEnd;
 		nodeStart = trace[pos];
@@ -354,7 +363,7 @@ Partial toMappings(const ga_graph& g, const std::string& sequence, int32_t score
 	m.from_length = (int64_t)(column(nodeEnd) - column(nodeStart));        // no +1 on the last mapping (:843)
 	m.to_length = (int64_t)(nodeEnd.row - beforeNode.row);
 	res.maps.push_back(m);
-	res.seqs.push_back(sequence.substr(nodeStart.row, nodeEnd.row - beforeNode.row));
+	res.seqs.push_back(spanOf(sequence, nodeStart.row, nodeEnd.row - beforeNode.row));
 	return res;
 }
 
@@ -925,7 +934,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		if (fwp.failed && bwp.failed) continue;
 		Partial merged = mergePartials(g, bwp, fwp);
 		uint64_t editBytes = 0;
-		for (const std::string& piece : merged.seqs) editBytes += piece.size();
+		for (const SeqSpan& piece : merged.seqs) editBytes += piece.len;
 		if (merged.maps.size() > mapAt[ri + 1] - mapAt[ri] || editBytes > editAt[ri + 1] - editAt[ri] || items.size() > traceAt[ri + 1] - traceAt[ri])
 		{
 			overflow.store(1);              // (a bound above is wrong: fail loudly instead of writing past a read's place)
@@ -940,8 +949,8 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		{
 			ga_mapping_t m = merged.maps[i];
 			m.edit_seq_off = editTop;
-			memcpy(allEdits + editTop, merged.seqs[i].data(), merged.seqs[i].size());
-			editTop += merged.seqs[i].size();
+			memcpy(allEdits + editTop, seq.data() + merged.seqs[i].pos, merged.seqs[i].len);
+			editTop += merged.seqs[i].len;
 			allMappings[mapAt[ri] + i] = m;
 		}
 		rr.n_trace = items.size();
