@@ -197,6 +197,82 @@ __global__ void __launch_bounds__(64) k_fill_staged(const uint32_t* __restrict__
 	}
 }
 
+// the staged loop with the end words in blocks of 8 columns per lane ([column / 8][lane][8 words]): a chunk reads its 8 previous end
+// words with two 16-byte loads and writes its own with two 16-byte stores instead of 8 + 8 four-byte accesses
+template <int U>
+__global__ void __launch_bounds__(64) k_fill_staged_blocked(const uint32_t* __restrict__ seq2, size_t genomeWords, const uint64_t* __restrict__ eqTab,
+                                              uint8_t* __restrict__ arena, size_t arenaBytesPerWave, uint32_t* __restrict__ endBuf, int steps, int colsPerSlice)
+{
+	static_assert(U == 8, "blocks of 8");
+	__shared__ uint64_t stage[64 * 25];
+	const int lane = threadIdx.x;
+	const size_t blk = blockIdx.x;
+	uint8_t* my = arena + blk * arenaBytesPerWave;
+	uint32_t* endPrev = endBuf + blk * 2 * (size_t)colsPerSlice * 64;
+	uint32_t* endCur = endPrev + (size_t)colsPerSlice * 64;
+	uint64_t e0 = eqTab[(blk * 4 + 0) * 64 + lane], e1 = eqTab[(blk * 4 + 1) * 64 + lane], e2 = eqTab[(blk * 4 + 2) * 64 + lane], e3 = eqTab[(blk * 4 + 3) * 64 + lane];
+	uint64_t vp = ~0ull, vn = 0;
+	int before = 1000 + lane;
+	size_t gcol = ((size_t)(blk * 64 + lane) * 7919u * 64u) % (genomeWords * 16 - (size_t)steps - 64);
+	uint32_t row = 0;
+	int c = 0;
+	uint4 curA, curB, nxtA, nxtB;
+	uint64_t bcur, bnxt;
+	auto blockAt = [&](uint32_t* plane, int col) { return (uint4*)(plane + ((size_t)(col >> 3) * 64 + lane) * 8); };
+	curA = blockAt(endPrev, c)[0]; curB = blockAt(endPrev, c)[1];
+	bcur = (uint64_t)seq2[gcol >> 4] | ((uint64_t)seq2[(gcol >> 4) + 1] << 32);
+	for (int k = 0; k < steps; k += U)
+	{
+		const bool last = c + U == colsPerSlice;
+		uint32_t* src = last ? endCur : endPrev;
+		const int cn = last ? 0 : c + U;
+		nxtA = blockAt(src, cn)[0]; nxtB = blockAt(src, cn)[1];
+		bnxt = (uint64_t)seq2[(gcol + U) >> 4] | ((uint64_t)seq2[((gcol + U) >> 4) + 1] << 32);
+		const uint32_t cur[8] = {curA.x, curA.y, curA.z, curA.w, curB.x, curB.y, curB.z, curB.w};
+		uint32_t ews[8];
+#pragma unroll
+		for (int i = 0; i < U; i++)
+		{
+			const int b = (int)(bcur >> (((gcol & 15) + i) * 2)) & 3;
+			const uint32_t pe = cur[i];
+			int calc = before + 1;
+			const int above = (int)(pe >> 3) + before - 3;
+			const bool re = calc > above && (pe & 4);
+			bitvector_column_step(vp, vn, before, re ? above : calc, b | ((pe & 8) ? 4 : 0), e0, e1, e2, e3);
+			const int end = before + __builtin_popcountll(vp) - __builtin_popcountll(vn);
+			const uint32_t ew = ((uint32_t)end << 3) | (uint32_t)(vp >> 63) | ((uint32_t)(vn >> 63) << 1);
+			uint64_t* st = stage + lane * 25 + i * 3;
+			st[0] = vp; st[1] = vn; st[2] = (uint64_t)(uint32_t)before | ((uint64_t)ew << 32);
+			ews[i] = ew;
+		}
+		blockAt(endCur, c)[0] = make_uint4(ews[0], ews[1], ews[2], ews[3]);
+		blockAt(endCur, c)[1] = make_uint4(ews[4], ews[5], ews[6], ews[7]);
+		__builtin_amdgcn_wave_barrier();
+		uint8_t* dst = my + (size_t)(row / 8) * (64 * 192);
+#pragma unroll
+		for (int j = 0; j < 12; j++)
+		{
+			const uint32_t q = (uint32_t)lane + 64u * j;
+			const uint32_t ln = q / 12u, part = q % 12u;
+			const uint64_t* sp = stage + ln * 25 + part * 2;
+			const uint64_t a = sp[0], bq = sp[1];
+			*(uint4*)(dst + (size_t)q * 16) = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)bq, (uint32_t)(bq >> 32));
+		}
+		__builtin_amdgcn_wave_barrier();
+		row += U;
+		gcol += U;
+		c += U;
+		if (c == colsPerSlice)
+		{
+			c = 0;
+			uint32_t* t = endPrev; endPrev = endCur; endCur = t;
+			e0 = e0 * 0x9E3779B97F4A7C15ull + 1; e1 ^= e0 >> 7; e2 += e1; e3 ^= e2 << 3;
+		}
+		curA = nxtA; curB = nxtB;
+		bcur = bnxt;
+	}
+}
+
 // traceback shape: one dependent record fetch per step (the next row depends on the fetched words)
 template <int R>
 __global__ void __launch_bounds__(64) k_trace(const uint8_t* __restrict__ arena, size_t arenaBytesPerWave, uint32_t* __restrict__ out, int steps, uint32_t rows)
@@ -270,6 +346,17 @@ template <int R, int LANES> int run(int cus, const uint32_t* seq2, size_t genome
 			bestS = ms < bestS ? ms : bestS;
 		}
 		printf("R=8 via LDS staging, coalesced block writes, unrolled steps: %8.3f ms = %.0f cycles per wave step at 2.4 GHz\n", bestS, bestS * 1e-3 * 2.4e9 / steps);
+		float bestB = 1e30f;
+		for (int rep = 0; rep < 3; rep++)
+		{
+			OK(hipEventRecord(a, 0));
+			hipLaunchKernelGGL((k_fill_staged_blocked<8>), dim3(waves), dim3(64), 0, 0, seq2, genomeWords, eqTab, arena, arenaBytesPerWave, endBuf, steps, colsPerSlice);
+			OK(hipEventRecord(b, 0));
+			OK(hipEventSynchronize(b));
+			float ms = 0; OK(hipEventElapsedTime(&ms, a, b));
+			bestB = ms < bestB ? ms : bestB;
+		}
+		printf("  ... and the end words in blocks of 8 columns per lane (two 16-byte accesses per chunk each way): %8.3f ms = %.0f cycles per wave step at 2.4 GHz\n", bestB, bestB * 1e-3 * 2.4e9 / steps);
 	}
 	if (LANES == 64)
 		for (int rep = 0; rep < 2; rep++)
