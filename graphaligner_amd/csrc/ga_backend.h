@@ -82,7 +82,7 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& g, const GaHmmTables&
 // rows: the row codes (one byte per padded read base) are only needed by the wave-per-read ladder kernels, so they are built and uploaded
 // on demand: the provider returns them (building them at its first call)
 typedef std::function<const std::vector<uint8_t>&()> GaRowsProvider;
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status);
 
 // the match words of ga_backend_create_batch from the row codes

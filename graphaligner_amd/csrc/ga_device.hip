@@ -254,7 +254,7 @@ struct DevBatch : GaBackendBatch
 		return 0;
 	}
 
-	int init(const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobsIn)
+	int init(const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobsIn)
 	{
 		HIP_OK(hipSetDevice(g->device));
 		HIP_OK(hipStreamCreate(&stream));
@@ -269,9 +269,9 @@ struct DevBatch : GaBackendBatch
 		L.ramp_bw = cfg.ramp_bw;
 		L.max_slices = std::max<uint32_t>(cfg.max_slices, 1);
 		GaJob* dJobs; uint64_t* eqDev;
-		if (alloc(&eqDev, eq.size())) return GA_E_DEVICE;
+		if (alloc(&eqDev, eqWords)) return GA_E_DEVICE;
 		if (alloc(&dJobs, jobs.size())) return GA_E_DEVICE;
-		HIP_OK(hipMemcpyAsync(eqDev, eq.data(), eq.size() * 8, hipMemcpyHostToDevice, stream));
+		HIP_OK(hipMemcpyAsync(eqDev, eq, eqWords * 8, hipMemcpyHostToDevice, stream));
 		HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GaJob), hipMemcpyHostToDevice, stream));
 		L.rows = nullptr;
 		L.jobs = dJobs;
@@ -570,14 +570,14 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, GaRowsProvider rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs,
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, GaRowsProvider rows, const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status)
 {
 	DevBatch* b = new DevBatch();
 	b->g = static_cast<DevGraph*>(graph);
 	b->cfg = cfg;
 	b->rowsProvider = rows;
-	int s = b->init(eq, jobs);
+	int s = b->init(eq, eqWords, jobs);
 	if (s) { delete b; *status = s; return nullptr; }
 	*status = 0;
 	return b;

@@ -13,6 +13,8 @@
 #include <sstream>
 #include <string>
 #include <atomic>
+#include <string_view>
+#include <sys/mman.h>
 #include <thread>
 #include <tuple>
 #include <unordered_map>
@@ -213,6 +215,9 @@ static int finalizeGraph(ga_graph* g, int overlap)
 // ================================================================================================
 namespace {
 
+// a read as the batch keeps it: a view into the batch's one buffer of read copies
+typedef std::string_view ReadSeq;
+
 struct Pos { uint32_t node, offset; uint64_t row; };
 typedef std::vector<Pos> Trace;
 
@@ -236,20 +241,24 @@ struct Partial { bool failed = true; int32_t score = 0; std::vector<ga_mapping_t
 struct ga_batch
 {
 	const ga_graph* g = nullptr;
-	std::vector<std::string> names, seqs;
+	std::vector<std::string> names;
+	std::vector<ReadSeq> seqs;            // into seqBuf
+	char* seqBuf = nullptr;
+	size_t seqBufBytes = 0;
 	std::vector<ReadPlan> reads;
 	std::vector<SeedPlan> seeds;
 	struct RowFill { size_t read; uint64_t off, n, padded, pos; bool backward; };
 	std::vector<RowFill> fills;         // where every job's rows come from
 	std::vector<uint8_t> rows;          // row codes, built when a kernel that wants them is about to run (see buildRows)
-	std::vector<uint64_t> eq;
+	std::unique_ptr<uint64_t[]> eq;       // match words per slice (not cleared first: every slice is written by the host threads)
+	size_t eqWords = 0;
 	std::vector<GaJob> jobs;
 	GaRunConfig cfg;
 	uint32_t flags = 0;
 	GaBackendBatch* dev = nullptr;
 	bool ran = false;
 	uint64_t columnUpdates = 0, slicesRun = 0, rowsTotal = 0;
-	~ga_batch() { delete dev; }
+	~ga_batch() { delete dev; free(seqBuf); }
 };
 
 // run `fn(fill, read sequence)` for every job's rows on the host threads
@@ -275,7 +284,7 @@ static void buildRows(ga_batch* b)
 	if (!b->rows.empty()) return;
 	const CharTables& T = tables();
 	b->rows.assign(b->rowsTotal + 64, 0);       // (+ slack so a 64-byte row load never leaves the buffer)
-	forEachFill(b, [&](const ga_batch::RowFill& f, const std::string& seq) {
+	forEachFill(b, [&](const ga_batch::RowFill& f, const ReadSeq& seq) {
 		const uint8_t padCode = T.rowCode[(uint8_t)'N'];
 		uint8_t* dst = b->rows.data() + f.off;
 		if (f.backward) for (uint64_t r = 0; r < f.n; r++) dst[r] = T.rowCode[T.complement[(uint8_t)seq[f.n - 1 - r]]];
@@ -316,13 +325,13 @@ int mapDeviceStatus(int s)
 
 // traceToAlignment (GraphAligner.h:782-847).  Node indices come straight from the device trace.
 // std::string::substr's clamping (the reference builds the pieces with substr, GraphAligner.h:829,845)
-static SeqSpan spanOf(const std::string& s, uint64_t pos, uint64_t len)
+static SeqSpan spanOf(const ReadSeq& s, uint64_t pos, uint64_t len)
 {
 	if (pos > s.size()) pos = s.size();
 	return SeqSpan{pos, std::min<uint64_t>(len, s.size() - pos)};
 }
 
-Partial toMappings(const ga_graph& g, const std::string& sequence, int32_t score, const Trace& trace)
+Partial toMappings(const ga_graph& g, const ReadSeq& sequence, int32_t score, const Trace& trace)
 {
 	Partial res;
 	res.score = score;
@@ -399,7 +408,7 @@ bool readMatches(char readChar, char graphChar)
 // getTraceInfoInner (GraphAligner.h:718-780).  Returns false where the reference's characterMatch
 // would assert: a diagonal step over a read character that is not IUPAC (e.g. 'U'), which can
 // survive the backward split because ReverseComplement maps it (CommonUtils.cpp:85-88).
-bool traceItemsInner(const ga_graph& g, const std::string& seq, const Trace& tr, std::vector<ga_trace_item_t>& out)
+bool traceItemsInner(const ga_graph& g, const ReadSeq& seq, const Trace& tr, std::vector<ga_trace_item_t>& out)
 {
 	for (size_t i = 1; i < tr.size(); i++)
 	{
@@ -433,7 +442,7 @@ bool traceItemsInner(const ga_graph& g, const std::string& seq, const Trace& tr,
 }
 
 // getTraceInfo (GraphAligner.h:690-716)
-bool traceItems(const ga_graph& g, const std::string& seq, const Trace& bw, const Trace& fw, std::vector<ga_trace_item_t>& out)
+bool traceItems(const ga_graph& g, const ReadSeq& seq, const Trace& bw, const Trace& fw, std::vector<ga_trace_item_t>& out)
 {
 	if (!bw.empty() && !traceItemsInner(g, seq, bw, out)) return false;
 	if (!bw.empty() && !fw.empty())
@@ -631,7 +640,18 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	std::vector<RowFill>& fills = b->fills;
 	uint64_t rowsTotal = 0;
 	{
-		// the batch keeps its own copy of the reads (the caller's buffers may go away before ga_batch_collect): copied on the host threads
+		// the batch keeps its own copy of the reads (the caller's buffers may go away before ga_batch_collect): ONE buffer, so that the
+		// copy is a few large first-touch faults (huge pages where the system gives them) instead of one allocation per read, filled
+		// on the host threads
+		std::vector<uint64_t> at(nReads + 1, 0);
+		for (size_t i = 0; i < nReads; i++) at[i + 1] = at[i] + reads[i].length;
+		b->seqBufBytes = (size_t)at[nReads] + 64;
+		void* mem = nullptr;
+		if (posix_memalign(&mem, 2u << 20, (b->seqBufBytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1)) != 0) { delete b; return GA_E_INVALID; }
+		b->seqBuf = (char*)mem;
+#ifdef MADV_HUGEPAGE
+		madvise(mem, (b->seqBufBytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1), MADV_HUGEPAGE);
+#endif
 		size_t nThreads = std::thread::hardware_concurrency();
 		if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
 		nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 16), nReads / 256 + 1));
@@ -640,14 +660,21 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		for (size_t t = 0; t < nThreads; t++)
 		{
 			const size_t lo = std::min(nReads, t * per), hi = std::min(nReads, lo + per);
-			if (lo < hi) pool.emplace_back([&, lo, hi]() { for (size_t i = lo; i < hi; i++) b->seqs[i].assign(reads[i].sequence, reads[i].length); });
+			if (lo < hi) pool.emplace_back([&, lo, hi]() {
+				for (size_t i = lo; i < hi; i++)
+				{
+					if (reads[i].length) memcpy(b->seqBuf + at[i], reads[i].sequence, reads[i].length);
+					b->seqs[i] = ReadSeq(b->seqBuf + at[i], reads[i].length);
+				}
+			});
 		}
 		for (auto& th : pool) th.join();
 	}
+	const auto tpc = std::chrono::steady_clock::now();
 	for (size_t i = 0; i < nReads; i++)
 	{
 		b->names[i] = reads[i].name ? reads[i].name : "";
-		const std::string& seq = b->seqs[i];
+		const ReadSeq& seq = b->seqs[i];
 		b->reads[i].firstSeed = b->seeds.size();
 		b->reads[i].nSeeds = seedOffsets[i + 1] - seedOffsets[i];
 		for (size_t k = seedOffsets[i]; k < seedOffsets[i + 1]; k++)
@@ -704,8 +731,10 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	}
 	b->rowsTotal = rowsTotal;
 	const auto tp1 = std::chrono::steady_clock::now();
-	b->eq.assign((rowsTotal / W + 1) * 5, 0);   // match words per slice for the lanes = reads kernel
-	forEachFill(b, [&](const RowFill& f, const std::string& seq) {
+	b->eqWords = (rowsTotal / W + 1) * 5;       // match words per slice for the lanes = reads kernel
+	b->eq.reset(new uint64_t[b->eqWords]);
+	for (int k = 0; k < 5; k++) b->eq[b->eqWords - 5 + k] = 0;              // (the slack slice behind the last job)
+	forEachFill(b, [&](const RowFill& f, const ReadSeq& seq) {
 		// 64 row codes at a time, straight into the slice's match words
 		const uint8_t padCode = T.rowCode[(uint8_t)'N'];
 		const uint8_t* fw = (const uint8_t*)seq.data() + f.pos;
@@ -717,18 +746,18 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 			if (f.backward) for (uint64_t k = 0; k < full; k++) buf[k] = T.rowCodeRc[*(bw - (r0 + k))];
 			else for (uint64_t k = 0; k < full; k++) buf[k] = T.rowCode[fw[r0 + k]];
 			for (uint64_t k = full; k < (uint64_t)W; k++) buf[k] = padCode;
-			ga_build_eq_words(buf, W, b->eq.data() + (f.off + r0) / W * 5);
+			ga_build_eq_words(buf, W, b->eq.get() + (f.off + r0) / W * 5);
 		}
 	});
 	int status = GA_S_OK;
 	const auto tp2 = std::chrono::steady_clock::now();
-	b->dev = ga_backend_create_batch(g->device, [b]() -> const std::vector<uint8_t>& { buildRows(b); return b->rows; }, b->eq, b->jobs, b->cfg, &status);
+	b->dev = ga_backend_create_batch(g->device, [b]() -> const std::vector<uint8_t>& { buildRows(b); return b->rows; }, b->eq.get(), b->eqWords, b->jobs, b->cfg, &status);
 	if (!b->dev) { delete b; return status ? status : GA_E_DEVICE; }
 	if (getenv("GA_DEBUG_COLLECT"))
 	{
 		const auto tp3 = std::chrono::steady_clock::now();
 		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-		fprintf(stderr, "graphaligner_amd: prepare: plan + copies %.1f ms, match words %.1f ms, device batch (alloc + upload) %.1f ms\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
+		fprintf(stderr, "graphaligner_amd: prepare: read copies %.1f ms, job plan %.1f ms, match words %.1f ms, device batch (alloc + upload) %.1f ms\n", ms(tp0, tpc), ms(tpc, tp1), ms(tp1, tp2), ms(tp2, tp3));
 	}
 	*out = b;
 	return GA_S_OK;
@@ -848,7 +877,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		rr.score = kMax;
 		rr.first_mapping = mapAt[ri];
 		rr.first_trace = traceAt[ri];
-		const std::string& seq = b->seqs[ri];
+		const ReadSeq& seq = b->seqs[ri];
 		const ReadPlan& rp = b->reads[ri];
 		if (rp.nSeeds == 0) { rr.status = GA_S_ASSERTION; continue; }          // assert(seedHits.size() > 0) (:412)
 		std::vector<std::tuple<uint64_t, uint64_t, uint32_t>> tried;

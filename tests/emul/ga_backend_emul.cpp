@@ -193,12 +193,12 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const std::vector<uint64_t>& eq, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
 {
 	EmulBatch* b = new EmulBatch();
 	b->g = static_cast<EmulGraph*>(g);
 	b->rowsProvider = rows;
-	b->eq = eq;
+	b->eq.assign(eq, eq + eqWords);
 	b->jobs = jobs;
 	b->cfg = cfg;
 	*status = 0;
