@@ -15,6 +15,7 @@
 #include <atomic>
 #include <string_view>
 #include <sys/mman.h>
+#include <mutex>
 #include <thread>
 #include <tuple>
 #include <unordered_map>
@@ -295,6 +296,58 @@ static void buildRows(ga_batch* b)
 
 namespace {
 
+// Large result arrays are recycled: unmapping a gigabyte when results are freed and faulting a fresh one in for the next batch costs
+// more than assembling the results.  A few buffers are kept (GA_RESULT_POOL_MB, default 4096; 0 = none), best fit first.
+class BufferPool
+{
+	struct Item { void* p; size_t cap; };
+	std::mutex lock;
+	std::vector<Item> items;
+	size_t held = 0;
+	static size_t limit()
+	{
+		static const size_t v = []() { const char* e = getenv("GA_RESULT_POOL_MB"); return (size_t)(e ? atoll(e) : 4096) << 20; }();
+		return v;
+	}
+public:
+	void* take(size_t bytes, size_t& cap)
+	{
+		{
+			std::lock_guard<std::mutex> g(lock);
+			int best = -1;
+			for (size_t i = 0; i < items.size(); i++)
+				if (items[i].cap >= bytes && items[i].cap <= 2 * bytes + (1u << 20) && (best < 0 || items[i].cap < items[(size_t)best].cap)) best = (int)i;
+			if (best >= 0)
+			{
+				Item it = items[(size_t)best];
+				items.erase(items.begin() + best);
+				held -= it.cap;
+				cap = it.cap;
+				return it.p;
+			}
+		}
+		cap = bytes + bytes / 16 + 64;
+		return malloc(cap);
+	}
+	void give(void* p, size_t cap)
+	{
+		if (!p) return;
+		{
+			std::lock_guard<std::mutex> g(lock);
+			if (cap >= (1u << 20) && held + cap <= limit() && items.size() < 16) { items.push_back(Item{p, cap}); held += cap; return; }
+		}
+		free(p);
+	}
+};
+static BufferPool& resultPool() { static BufferPool* pool = new BufferPool();  return *pool; }    // (never destroyed: results may be freed at exit)
+struct PooledBuffer
+{
+	void* p = nullptr;
+	size_t cap = 0;
+	void* get(size_t bytes) { resultPool().give(p, cap); p = resultPool().take(bytes, cap); return p; }
+	~PooledBuffer() { resultPool().give(p, cap); }
+};
+
 struct ResultsOwner
 {
 	ga_results_t pub;
@@ -302,11 +355,8 @@ struct ResultsOwner
 	std::vector<ga_mapping_t> mappings;
 	std::vector<char> edits;
 	std::vector<ga_trace_item_t> trace;
-	// the stitched arrays of a whole batch: allocated without being cleared first (hundreds of MB)
-	std::unique_ptr<ga_read_result_t[]> allReads;
-	std::unique_ptr<ga_mapping_t[]> allMappings;
-	std::unique_ptr<char[]> allEdits;
-	std::unique_ptr<ga_trace_item_t[]> allTrace;
+	// the arrays of a whole batch (hundreds of MB, not cleared first): from the process-wide pool below, back to it with the results
+	PooledBuffer allReads, allMappings, allEdits, allTrace;
 };
 
 int mapDeviceStatus(int s)
@@ -855,14 +905,11 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		editAt[ri + 1] = editAt[ri] + b->seqs[ri].size() + 8;
 		traceAt[ri + 1] = traceAt[ri] + (wantTraceAll ? items : 0);
 	}
-	R->allReads.reset(new ga_read_result_t[nReadsAll + 1]);
-	R->allMappings.reset(new ga_mapping_t[mapAt[nReadsAll] + 1]);
-	R->allEdits.reset(new char[editAt[nReadsAll] + 1]);
-	R->allTrace.reset(new ga_trace_item_t[traceAt[nReadsAll] + 1]);
-	ga_read_result_t* const allReads = R->allReads.get();
-	ga_mapping_t* const allMappings = R->allMappings.get();
-	char* const allEdits = R->allEdits.get();
-	ga_trace_item_t* const allTrace = R->allTrace.get();
+	ga_read_result_t* const allReads = (ga_read_result_t*)R->allReads.get((nReadsAll + 1) * sizeof(ga_read_result_t));
+	ga_mapping_t* const allMappings = (ga_mapping_t*)R->allMappings.get((mapAt[nReadsAll] + 1) * sizeof(ga_mapping_t));
+	char* const allEdits = (char*)R->allEdits.get(editAt[nReadsAll] + 1);
+	ga_trace_item_t* const allTrace = (ga_trace_item_t*)R->allTrace.get((traceAt[nReadsAll] + 1) * sizeof(ga_trace_item_t));
+	if (!allReads || !allMappings || !allEdits || !allTrace) { delete R; b->dev->fetchDone(); return GA_E_INVALID; }
 	std::atomic<int> overflow{0};
 	std::atomic<uint64_t> columnUpdatesAll{0};
 
