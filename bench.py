@@ -149,7 +149,7 @@ def main():
     st = batch.stats()
     # the host stages once more on a second batch of the same reads: the first prepare / collect of a process also pay for the pinned
     # download buffer and the first touch of their arrays (the PCIe-inclusive figure in detail is the better of the two)
-    if rank == 0:
+    if rank == 0 and args.pipeline_chunks > 0:       # (--pipeline-chunks 0: no launches beyond the timed ones, for profiling runs)
         rs2 = binding.ReadSet(reads, seeds)           # (the arrays a C caller holds; the Python lists are the simulator's)
         t0 = time.time()
         batch2 = graph.prepare(rs2, None, args.bandwidth, 0)

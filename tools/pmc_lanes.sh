@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 O=gpurun_out/pmc_lanes
 rm -rf $O && mkdir -p $O
 run() { name=$1; shift; pmc=$1; shift
-  rocprofv3 --pmc $pmc --output-format csv -d $O/$name -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 "$@" > $O/$name.json 2> $O/$name.err; echo "$name done"; }
+  rocprofv3 --pmc $pmc --output-format csv -d $O/$name -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --accuracy 0 --pipeline-chunks 0 "$@" > $O/$name.json 2> $O/$name.err; echo "$name done"; }
 run a "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "$@"
 run b "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES" "$@"
 run fetch "FETCH_SIZE" "$@"

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 O=gpurun_out/pmc_lat
 rm -rf $O && mkdir -p $O
 run() { name=$1; shift; pmc=$1; shift
-  rocprofv3 --pmc $pmc --output-format csv -d $O/$name -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --accuracy 0 "$@" > $O/$name.json 2> $O/$name.err; echo "$name rc=$?"; }
+  rocprofv3 --pmc $pmc --output-format csv -d $O/$name -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --accuracy 0 --pipeline-chunks 0 "$@" > $O/$name.json 2> $O/$name.err; echo "$name rc=$?"; }
 run a "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VMEM" "$@"
 run b "SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "$@"
 run c "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES" "$@"

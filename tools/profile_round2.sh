@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/prof2
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --check 0 > $O/stats_bench.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 --check 0 --accuracy 0 --pipeline-chunks 0 > $O/stats_bench.json 2> $O/stats.err
 echo "stats done"
 bash tools/pmc_lanes.sh > $O/pmc.log 2>&1
 cp gpurun_out/pmc_lanes/summary.json $O/pmc_summary.json
