@@ -243,6 +243,23 @@ def case_multiple_seeds_per_read(lib_path=None):
     pc.check_parity(g.nodes, g.edges, reads, multi, 35, lib_path=lib_path, ctx="multiseed")
 
 
+def case_results_without_trace_items(lib_path=None):
+    """the same comparisons with flags = 0 (no TraceItem lists: what bench.py and a production caller ask for): the results are
+    assembled without the trace-item pass, except for reads with a non-IUPAC character, which the reference's eager TraceItem
+    construction (GraphAligner.h:463) still turns into an assertion"""
+    g = synth.bubble_graph(30000, node_len=32, seed=27)
+    reads, seeds = synth.simulate_reads(g, 10, 1500, seed=6, mid_seed=True)
+    other, oseeds = synth.simulate_reads(g, 10, 1500, seed=60)
+    b = bytearray(reads[3].encode()); b[400] = ord("X"); reads[3] = b.decode()
+    b = bytearray(reads[4].encode()); b[10] = ord("n"); b[900] = ord("R"); reads[4] = b.decode()
+    multi = [[s, (o[0], 600, o[2])] if k % 3 == 0 else s for k, (s, o) in enumerate(zip(seeds, oseeds))]
+    devs, oras = pc.run_both(g.nodes, g.edges, reads, multi, 35, lib_path=lib_path, trace=False)
+    assert any(o["status"] != 0 for o in oras) and any(not o["failed"] for o in oras)
+    for i, (d, o) in enumerate(zip(devs, oras)):
+        assert d["trace"].shape[0] == 0
+        pc.compare_read(d, dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "no trace items, read %d" % i)
+
+
 def case_unknown_seed_node_reports_bad_seed(lib_path=None):
     g = synth.linear_graph(5000, node_len=64, seed=1)
     reads, seeds = synth.simulate_reads(g, 2, 600, seed=1)

@@ -56,6 +56,10 @@ def test_multiple_seeds_per_read(lib):
     cases.case_multiple_seeds_per_read(lib)
 
 
+def test_results_without_trace_items(lib):
+    cases.case_results_without_trace_items(lib)
+
+
 def test_unknown_seed_node_reports_bad_seed(lib):
     cases.case_unknown_seed_node_reports_bad_seed(lib)
 

@@ -68,6 +68,10 @@ def test_multiple_seeds_per_read():
     cases.case_multiple_seeds_per_read()
 
 
+def test_results_without_trace_items():
+    cases.case_results_without_trace_items()
+
+
 def test_unknown_seed_node_reports_bad_seed():
     cases.case_unknown_seed_node_reports_bad_seed()
 
