@@ -911,7 +911,88 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	ga_trace_item_t* const allTrace = (ga_trace_item_t*)R->allTrace.get((traceAt[nReadsAll] + 1) * sizeof(ga_trace_item_t));
 	if (!allReads || !allMappings || !allEdits || !allTrace) { delete R; b->dev->fetchDone(); return GA_E_INVALID; }
 	std::atomic<int> overflow{0};
-	std::atomic<uint64_t> columnUpdatesAll{0};
+	std::atomic<uint64_t> columnUpdatesAll{0}, forwardOnlyReads{0};
+
+	// The common shape -- one seed at the read's first base, so one forward job, and no TraceItem list wanted -- without the detour
+	// over a cell list: the moves are replayed once, node runs are noted as they end, and the mappings are written from the runs.
+	// Same result as the general code below (getPiecewiseTracesFromSplit :3039-3098 without a backward part, traceToAlignment
+	// :782-847, mergeAlignments with a failed first part); anything unusual (a dummy node on the path) is left to that code.
+	struct NodeRun { uint32_t node, firstOffset, lastOffset; uint64_t firstRow, lastRow; };
+	auto forwardOnly = [&](size_t ri, ga_read_result_t& rr) -> bool {
+		const ReadPlan& rp = b->reads[ri];
+		if (rp.nSeeds != 1 || wantTraceAll) return false;
+		const SeedPlan& sp = b->seeds[rp.firstSeed];
+		if (sp.early != GA_S_OK || sp.bwJob >= 0 || sp.fwJob < 0 || sp.pos != 0) return false;
+		const GaJobOut& o = outs[sp.fwJob];
+		if (o.status != GA_OK) return false;
+		const ReadSeq& seq = b->seqs[ri];
+		for (char c : seq) if (tables().rowCode[(uint8_t)c] & GA_ROW_INVALID) return false;     // (the reference's eager TraceItem pass asserts on these)
+		if (o.n_valid == 0) { rr.column_updates += o.n_columns; rr.status = GA_S_OK; return true; }     // nothing kept: both parts fail (rr stays failed)
+		const uint64_t traceable = seq.size() - sp.pos - g.dbgOverlap;
+		const uint64_t dummyEndAsIndex = g.bases.size() - 1;
+		thread_local std::vector<NodeRun> runs;
+		runs.clear();
+		const uint8_t* mv = moves + o.trace_off;
+		Pos p{o.start_node, o.start_offset, o.start_row};
+		auto note = [&](const Pos& c) -> bool {
+			if (c.row >= traceable) return true;                                  // the trace's tail beyond the read's end is dropped (:3051-3055)
+			if (c.node == 0 || c.node == dummyEndAsIndex) return false;
+			if (!runs.empty() && runs.back().node == c.node) { runs.back().firstOffset = c.offset; runs.back().firstRow = c.row; }
+			else runs.push_back(NodeRun{c.node, c.offset, c.offset, c.row, c.row});
+			return true;
+		};
+		if (!note(p)) return false;
+		for (uint32_t i = 0; i < o.trace_len; i++)
+		{
+			const int code = mv[i] & 3, via = mv[i] >> 2;
+			if (code != GA_MOVE_LEFT) p.row -= 1;
+			if (code != GA_MOVE_UP)
+			{
+				if (p.offset > 0) p.offset -= 1;
+				else
+				{
+					p.node = g.inNeighbor(p.node, (uint32_t)via);
+					p.offset = g.nodeLen(p.node) - 1;
+				}
+			}
+			if (!note(p)) return false;
+		}
+		rr.column_updates += o.n_columns;
+		rr.status = GA_S_OK;
+		if (runs.empty()) return true;                                         // an empty trace fails (:786-790)
+		const size_t nRuns = runs.size();
+		if (nRuns > mapAt[ri + 1] - mapAt[ri]) { overflow.store(1); rr.status = GA_E_DEVICE; return true; }
+		// the runs were noted from the read's end to its start
+		uint64_t editTop = editAt[ri];
+		uint64_t beforeRow = runs[nRuns - 1].firstRow;
+		for (size_t k = 0; k < nRuns; k++)
+		{
+			const NodeRun& r = runs[nRuns - 1 - k];
+			ga_mapping_t m;
+			memset(&m, 0, sizeof(m));
+			m.rank = (int32_t)k;
+			m.node_id = g.ids[r.node];
+			m.is_reverse = g.reverse[r.node];
+			m.offset = k == 0 ? r.firstOffset : 0;
+			m.from_length = (int64_t)r.lastOffset - (int64_t)r.firstOffset + (k + 1 < nRuns ? 1 : 0);        // no +1 on the last mapping (:843)
+			m.to_length = (int64_t)(r.lastRow - beforeRow);
+			const SeqSpan piece = spanOf(seq, r.firstRow, r.lastRow - beforeRow);
+			m.edit_seq_off = editTop;
+			if (piece.len > editAt[ri + 1] - editTop) { overflow.store(1); rr.status = GA_E_DEVICE; return true; }
+			memcpy(allEdits + editTop, seq.data() + piece.pos, piece.len);
+			editTop += piece.len;
+			allMappings[mapAt[ri] + k] = m;
+			beforeRow = r.lastRow;
+		}
+		rr.failed = 0;
+		rr.score = o.score;
+		rr.n_mappings = nRuns;
+		rr.n_trace = 0;
+		rr.query_position = 0;
+		rr.alignment_start = 0;
+		rr.alignment_end = (uint64_t)o.n_valid * W;
+		return true;
+	};
 
 	auto work = [&](size_t lo, size_t hi) {
 	std::vector<ga_trace_item_t> items;
@@ -927,6 +1008,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		const ReadSeq& seq = b->seqs[ri];
 		const ReadPlan& rp = b->reads[ri];
 		if (rp.nSeeds == 0) { rr.status = GA_S_ASSERTION; continue; }          // assert(seedHits.size() > 0) (:412)
+		if (forwardOnly(ri, rr)) { columnUpdates += rr.column_updates; forwardOnlyReads++; continue; }
 		std::vector<std::tuple<uint64_t, uint64_t, uint32_t>> tried;
 		bool have = false;
 		uint64_t bestEstimate = 0, bestPos = 0;
@@ -1071,7 +1153,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	{
 		const auto t3 = std::chrono::steady_clock::now();
 		auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-		fprintf(stderr, "graphaligner_amd: collect: fetch %.1f ms (%zu trace bytes), assembly %.1f ms on %zu threads, hand-over %.1f ms\n", ms(t0, t1), (size_t)nMoveBytes, ms(t1, t2), nThreads, ms(t2, t3));
+		fprintf(stderr, "graphaligner_amd: collect: fetch %.1f ms (%zu trace bytes), assembly %.1f ms on %zu threads (%llu of %zu reads on the forward-only path), hand-over %.1f ms\n", ms(t0, t1), (size_t)nMoveBytes, ms(t1, t2), nThreads, (unsigned long long)forwardOnlyReads.load(), nReadsAll, ms(t2, t3));
 	}
 	return GA_S_OK;
 }

@@ -258,6 +258,17 @@ def case_results_without_trace_items(lib_path=None):
     for i, (d, o) in enumerate(zip(devs, oras)):
         assert d["trace"].shape[0] == 0
         pc.compare_read(d, dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "no trace items, read %d" % i)
+    # one seed at the read's first base: the shape the result assembly has its own path for (one forward job, node runs noted while
+    # the moves are replayed) -- with IUPAC characters, a read too short to align, a damaged read that stops early, 1-bp SNP nodes
+    for graph in (g, synth.SynthGraph(synth.random_genome(20000, 71), node_len=16, snp_every=30, indel_every=300, seed=72), synth.linear_graph(20000, node_len=64, seed=73)):
+        reads, seeds = synth.simulate_reads(graph, 12, 1800, seed=9)
+        b = bytearray(reads[1].encode()); b[5] = ord("N"); b[700] = ord("y"); reads[1] = b.decode()
+        reads[2] = reads[2][:150]
+        reads[5] = damaged_reads([reads[5]], np.random.default_rng(3))[0]
+        b = bytearray(reads[7].encode()); b[900] = ord("X"); reads[7] = b.decode()
+        devs, oras = pc.run_both(graph.nodes, graph.edges, reads, seeds, 35, lib_path=lib_path, trace=False)
+        for i, (d, o) in enumerate(zip(devs, oras)):
+            pc.compare_read(d, dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "forward only, read %d" % i)
 
 
 def case_unknown_seed_node_reports_bad_seed(lib_path=None):
