@@ -933,18 +933,10 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		thread_local std::vector<NodeRun> runs;
 		runs.clear();
 		const uint8_t* mv = moves + o.trace_off;
+		const uint32_t nMoves = o.trace_len;
 		Pos p{o.start_node, o.start_offset, o.start_row};
-		auto note = [&](const Pos& c) -> bool {
-			if (c.row >= traceable) return true;                                  // the trace's tail beyond the read's end is dropped (:3051-3055)
-			if (c.node == 0 || c.node == dummyEndAsIndex) return false;
-			if (!runs.empty() && runs.back().node == c.node) { runs.back().firstOffset = c.offset; runs.back().firstRow = c.row; }
-			else runs.push_back(NodeRun{c.node, c.offset, c.offset, c.row, c.row});
-			return true;
-		};
-		if (!note(p)) return false;
-		for (uint32_t i = 0; i < o.trace_len; i++)
-		{
-			const int code = mv[i] & 3, via = mv[i] >> 2;
+		auto step = [&](uint8_t m) {
+			const int code = m & 3, via = m >> 2;
 			if (code != GA_MOVE_LEFT) p.row -= 1;
 			if (code != GA_MOVE_UP)
 			{
@@ -955,7 +947,34 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 					p.offset = g.nodeLen(p.node) - 1;
 				}
 			}
-			if (!note(p)) return false;
+		};
+		uint32_t i = 0;
+		while (p.row >= traceable && i < nMoves) step(mv[i++]);                  // the trace's tail beyond the read's end is dropped (:3051-3055)
+		if (p.row < traceable)
+		{
+			// a run is opened at its last cell (the first one met on the way back) and closed, with its first cell, when the path
+			// leaves the node; eight diagonal steps inside a node are taken at once
+			if (p.node == 0 || p.node == dummyEndAsIndex) return false;
+			runs.push_back(NodeRun{p.node, p.offset, p.offset, p.row, p.row});
+			const uint64_t eightDiagonals = 0x0101010101010101ull * (uint64_t)GA_MOVE_DIAG;
+			while (i < nMoves)
+			{
+				if (i + 8 <= nMoves && p.offset >= 8)
+				{
+					uint64_t w;
+					memcpy(&w, mv + i, 8);
+					if (w == eightDiagonals) { p.offset -= 8; p.row -= 8; i += 8; continue; }
+				}
+				const Pos before = p;
+				step(mv[i++]);
+				if (p.node != before.node)
+				{
+					runs.back().firstOffset = before.offset; runs.back().firstRow = before.row;
+					if (p.node == 0 || p.node == dummyEndAsIndex) return false;
+					runs.push_back(NodeRun{p.node, p.offset, p.offset, p.row, p.row});
+				}
+			}
+			runs.back().firstOffset = p.offset; runs.back().firstRow = p.row;
 		}
 		rr.column_updates += o.n_columns;
 		rr.status = GA_S_OK;
