@@ -130,11 +130,13 @@ def case_gfa_overlap(lib_path=None):
                 seeds.append((segs[b][0], len(pre), False))
         g = binding.Graph(gfa=gfa, lib_path=lib_path)
         devs = g.align(reads, seeds, 35, 0, flags=binding.GA_F_TRACE)
+        plain = g.align(reads, seeds, 35, 0, flags=0)          # (no TraceItem lists: the forward-only assembly path for the seeds at 0)
         og = ob.OracleGraph.from_gfa_segments(segs, links, k)
         n_ok = 0
         for i, (r, sd) in enumerate(zip(reads, seeds)):
             o = og.align(r, [sd], 35)
             pc.compare_read(devs[i], o, "overlap %d read %d" % (k, i))
+            pc.compare_read(plain[i], dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "overlap %d read %d without trace items" % (k, i))
             n_ok += int(o["status"] == 0 and not o["failed"])
         assert n_ok >= 8, n_ok
 
