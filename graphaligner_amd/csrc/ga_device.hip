@@ -390,6 +390,17 @@ struct DevBatch : GaBackendBatch
 				uint64_t lo = ~0ull, hi = 0, n = 0; double life = 0, cyc = 0, lateStart = 0;
 				for (auto& o : outs) if (o.stamps[1]) { lo = std::min(lo, o.stamps[0]); hi = std::max(hi, o.stamps[1]); }
 				for (auto& o : outs) if (o.stamps[1]) { n++; life += (double)(o.stamps[1] - o.stamps[0]); cyc += (double)o.stamps[4]; lateStart = std::max(lateStart, (double)(o.stamps[0] - lo)); }
+				{
+					// the spread of the waves' lifetimes, and what goes with a long one (fill steps are not known per wave; traceback rounds are)
+					std::vector<std::pair<double, uint64_t>> lives;
+					for (auto& o : outs) if (o.stamps[1]) lives.push_back({(double)(o.stamps[1] - o.stamps[0]) / 1e5, o.stamps[7]});
+					std::sort(lives.begin(), lives.end());
+					auto at = [&](double q) { return lives[(size_t)(q * (lives.size() - 1))]; };
+					if (!lives.empty()) fprintf(stderr, "graphaligner_amd: wave life ms p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f; traceback rounds of the p10 / p50 / p99 / max wave: %llu / %llu / %llu / %llu, fast iterations %llu / %llu / %llu / %llu\n",
+						at(0.1).first, at(0.5).first, at(0.9).first, at(0.99).first, at(1.0).first,
+						(unsigned long long)(at(0.1).second & 0xffffffffu), (unsigned long long)(at(0.5).second & 0xffffffffu), (unsigned long long)(at(0.99).second & 0xffffffffu), (unsigned long long)(at(1.0).second & 0xffffffffu),
+						(unsigned long long)(at(0.1).second >> 32), (unsigned long long)(at(0.5).second >> 32), (unsigned long long)(at(0.99).second >> 32), (unsigned long long)(at(1.0).second >> 32));
+				}
 				if (n) fprintf(stderr, "graphaligner_amd: %llu waves: first start to last end %.3f ms, mean wave life %.3f ms = %.1f M shader cycles (%.2f GHz), latest start %.3f ms after the first\n",
 				               (unsigned long long)n, (hi - lo) / 1e5, life / n / 1e5, cyc / n / 1e6, cyc / life / 10.0, lateStart / 1e5);
 			}
