@@ -19,6 +19,7 @@ def main(argv=None, quiet=False):
     ap.add_argument("--reads", type=int, default=24)
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--emul", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="flags = 0: no TraceItem lists (the result assembly's forward-only path for seeds at the first base)")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="align only these trials (the others are still generated, so the random stream is the same)")
     args = ap.parse_args(argv)
     import numpy as np
@@ -65,7 +66,9 @@ def main(argv=None, quiet=False):
             reads[k] = b.decode()
         if args.only is not None and trial not in args.only:
             continue
-        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, ramp=ramp, lib_path=lib)
+        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, ramp=ramp, lib_path=lib, trace=not args.no_trace)
+        if args.no_trace:
+            oras = [dict(o, trace=np.zeros((0, 7), dtype=np.int64)) for o in oras]
         for i, (d, o) in enumerate(zip(devs, oras)):
             stats["reads"] += 1
             stats["dev_status"][str(d["status"])] = stats["dev_status"].get(str(d["status"]), 0) + 1
