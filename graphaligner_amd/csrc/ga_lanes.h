@@ -367,7 +367,15 @@ template <int N> GAL_FN int project_band(const GaDevGraph& g, const LaneMem& m, 
 	struct Rec6 { uint32_t w[6]; };
 	auto pushOut = [&](const Rec6& r, uint32_t node, int prio) -> int {
 		const uint32_t deg = r.w[1] >> 16;
-		if (deg <= 4) { for (uint32_t e = 0; e < deg; e++) if (!heap_push<N>(l, heapSize, r.w[2 + e], prio)) return GA_CAP_HEAP; }
+		if (deg <= 4)
+		{
+			// (the neighbour is picked by compares: indexing the record with the loop counter would put it in scratch memory)
+			for (uint32_t e = 0; e < deg; e++)
+			{
+				const uint32_t nbr = e == 0 ? r.w[2] : e == 1 ? r.w[3] : e == 2 ? r.w[4] : r.w[5];
+				if (!heap_push<N>(l, heapSize, nbr, prio)) return GA_CAP_HEAP;
+			}
+		}
 		else for (uint32_t e = g.out_off[node]; e < g.out_off[node + 1]; e++) if (!heap_push<N>(l, heapSize, g.out_nbr[e], prio)) return GA_CAP_HEAP;
 		return GA_OK;
 	};
