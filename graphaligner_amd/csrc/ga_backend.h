@@ -50,6 +50,7 @@ struct GaRunConfig
 	int initial_bw = 0, ramp_bw = 0;
 	uint32_t max_slices = 0;            // max over jobs of n_rows / 64
 	uint32_t max_rows = 0;
+	uint32_t emit_runs = 0;             // 1: no result of the batch needs a cell list: the lanes = reads kernel hands back node runs instead of moves
 };
 
 struct GaRunStats

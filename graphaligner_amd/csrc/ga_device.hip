@@ -351,6 +351,7 @@ struct DevBatch : GaBackendBatch
 		P.next_group = L.next_job;
 		P.traces = L.traces; P.trace_top = L.trace_top; P.trace_pool_cap = L.trace_pool_cap;
 		P.initial_bw = L.initial_bw; P.ramp_bw = L.ramp_bw;
+		P.emit_runs = cfg.emit_runs;
 		uint32_t maxRows = 0;
 		for (uint32_t i : list) maxRows = std::max(maxRows, jobs[i].n_rows);
 		P.max_slices = std::max<uint32_t>(maxRows / 64, 1);

@@ -251,6 +251,7 @@ struct ga_batch
 	struct RowFill { size_t read; uint64_t off, n, padded, pos; bool backward; };
 	std::vector<RowFill> fills;         // where every job's rows come from
 	std::vector<uint8_t> rows;          // row codes, built when a kernel that wants them is about to run (see buildRows)
+	std::atomic<int> anyInvalidRow{0};    // some read has a character outside IUPAC (its results need the TraceItem pass)
 	std::unique_ptr<uint64_t[]> eq;       // match words per slice (not cleared first: every slice is written by the host threads)
 	size_t eqWords = 0;
 	std::vector<GaJob> jobs;
@@ -754,6 +755,7 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 				job.rows_off = rowsTotal;
 				job.n_rows = (uint32_t)pad64(n);
 				job.seed_node = bwNode;
+				job.trace_rows = (uint32_t)(n - g->dbgOverlap); job.reserved = 0;       // = sp.pos (:3069)
 				rowsTotal += job.n_rows;
 				fills.push_back(RowFill{i, job.rows_off, n, job.n_rows, 0, true});
 				sp.bwJob = (int64_t)b->jobs.size();
@@ -766,6 +768,7 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 				job.rows_off = rowsTotal;
 				job.n_rows = (uint32_t)pad64(n);
 				job.seed_node = fwNode;
+				job.trace_rows = n >= (uint64_t)g->dbgOverlap ? (uint32_t)(n - g->dbgOverlap) : 0u; job.reserved = 0;   // (:3051)
 				rowsTotal += job.n_rows;
 				fills.push_back(RowFill{i, job.rows_off, n, job.n_rows, sp.pos, false});
 				sp.fwJob = (int64_t)b->jobs.size();
@@ -796,9 +799,20 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 			if (f.backward) for (uint64_t k = 0; k < full; k++) buf[k] = T.rowCodeRc[*(bw - (r0 + k))];
 			else for (uint64_t k = 0; k < full; k++) buf[k] = T.rowCode[fw[r0 + k]];
 			for (uint64_t k = full; k < (uint64_t)W; k++) buf[k] = padCode;
-			ga_build_eq_words(buf, W, b->eq.get() + (f.off + r0) / W * 5);
+			uint64_t* words = b->eq.get() + (f.off + r0) / W * 5;
+			ga_build_eq_words(buf, W, words);
+			if (words[4] & 8u) b->anyInvalidRow.store(1, std::memory_order_relaxed);
 		}
 	});
+	// Node runs instead of moves from the traceback when no result of the batch needs a cell list: no TraceItem lists wanted, every
+	// read with one seed at its first base (one forward job: no backward part to mirror, no later seed to test against the cells
+	// of an earlier one, GraphAligner.h:423-429), no character whose TraceItem the reference would assert on
+	{
+		bool runs = (flags & GA_F_TRACE) == 0 && b->anyInvalidRow.load() == 0 && !(getenv("GA_RUNS") && atoi(getenv("GA_RUNS")) == 0);
+		for (size_t i = 0; i < nReads && runs; i++) if (b->reads[i].nSeeds > 1) runs = false;
+		for (const SeedPlan& sp : b->seeds) if (sp.bwJob >= 0 || (sp.fwJob >= 0 && sp.pos != 0)) { runs = false; break; }
+		b->cfg.emit_runs = runs ? 1u : 0u;
+	}
 	int status = GA_S_OK;
 	const auto tp2 = std::chrono::steady_clock::now();
 	b->dev = ga_backend_create_batch(g->device, [b]() -> const std::vector<uint8_t>& { buildRows(b); return b->rows; }, b->eq.get(), b->eqWords, b->jobs, b->cfg, &status);
@@ -836,6 +850,7 @@ int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out)
 	out->jobs_retried = st.jobs_retried;
 	for (int k = 0; k < 8; k++) out->stamps[k] = st.stamps[k];
 	out->column_updates = b->columnUpdates;
+	out->reserved = (int32_t)b->cfg.emit_runs;
 	out->slices = b->slicesRun;
 	return GA_S_OK;
 }
@@ -860,10 +875,12 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	// The device hands back, per job, the cell the traceback starts in and one byte per backward move
 	// (GA_MOVE_*; a move out of a node's first column names the in-neighbour it enters).  Replaying
 	// them gives the reference's trace, which runs from row 0 upwards (getTraceFromTable :949-952).
+	std::atomic<int> overflow{0};
 	auto deviceTrace = [&](int64_t job) {
 		Trace t;
 		const GaJobOut& o = outs[job];
 		if (o.n_valid == 0) return t;
+		if (o.reserved3 == 1) { overflow.store(1); return t; }      // (node runs, not moves: only batches that need no cell list get them)
 		const uint8_t* mv = moves + o.trace_off;
 		t.resize((size_t)o.trace_len + 1);
 		Pos p{o.start_node, o.start_offset, o.start_row};
@@ -910,7 +927,6 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	char* const allEdits = (char*)R->allEdits.get(editAt[nReadsAll] + 1);
 	ga_trace_item_t* const allTrace = (ga_trace_item_t*)R->allTrace.get((traceAt[nReadsAll] + 1) * sizeof(ga_trace_item_t));
 	if (!allReads || !allMappings || !allEdits || !allTrace) { delete R; b->dev->fetchDone(); return GA_E_INVALID; }
-	std::atomic<int> overflow{0};
 	std::atomic<uint64_t> columnUpdatesAll{0}, forwardOnlyReads{0};
 
 	// The common shape -- one seed at the read's first base, so one forward job, and no TraceItem list wanted -- without the detour
@@ -932,6 +948,15 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		const uint64_t dummyEndAsIndex = g.bases.size() - 1;
 		thread_local std::vector<NodeRun> runs;
 		runs.clear();
+		if (o.reserved3 == 1)
+		{
+			// the traceback's own node runs (five words each), from the read's end to its start like the replay's
+			const uint32_t* rec = (const uint32_t*)(moves + o.trace_off);
+			runs.resize(o.trace_len);
+			for (uint32_t k = 0; k < o.trace_len; k++, rec += 5) runs[k] = NodeRun{rec[0], rec[1], rec[3], rec[2], rec[4]};
+		}
+		else
+		{
 		const uint8_t* mv = moves + o.trace_off;
 		const uint32_t nMoves = o.trace_len;
 		Pos p{o.start_node, o.start_offset, o.start_row};
@@ -954,7 +979,6 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		{
 			// a run is opened at its last cell (the first one met on the way back) and closed, with its first cell, when the path
 			// leaves the node; eight diagonal steps inside a node are taken at once
-			if (p.node == 0 || p.node == dummyEndAsIndex) return false;
 			runs.push_back(NodeRun{p.node, p.offset, p.offset, p.row, p.row});
 			const uint64_t eightDiagonals = 0x0101010101010101ull * (uint64_t)GA_MOVE_DIAG;
 			while (i < nMoves)
@@ -970,12 +994,18 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 				if (p.node != before.node)
 				{
 					runs.back().firstOffset = before.offset; runs.back().firstRow = before.row;
-					if (p.node == 0 || p.node == dummyEndAsIndex) return false;
 					runs.push_back(NodeRun{p.node, p.offset, p.offset, p.row, p.row});
 				}
 			}
 			runs.back().firstOffset = p.offset; runs.back().firstRow = p.row;
 		}
+		}
+		// traceToAlignment's dummy nodes (:786-800, 816): cells of the start dummy at the read's start are skipped, a path that begins
+		// in the end dummy fails, and the path is cut where it first enters the end dummy
+		while (!runs.empty() && runs.back().node == 0) runs.pop_back();
+		if (!runs.empty() && runs.back().node == dummyEndAsIndex) runs.clear();
+		for (size_t k = runs.size(); k-- > 0;)
+			if (runs[k].node == dummyEndAsIndex) { runs.erase(runs.begin(), runs.begin() + (long)k + 1); break; }
 		rr.column_updates += o.n_columns;
 		rr.status = GA_S_OK;
 		if (runs.empty()) return true;                                         // an empty trace fails (:786-790)

@@ -74,6 +74,8 @@ struct GaLanesLaunch
 	uint32_t max_slices;
 	uint32_t cap_moves;            // traceback moves per lane (staging)
 	int32_t initial_bw, ramp_bw;
+	uint32_t emit_runs;            // 1: the traceback hands back node runs instead of moves (batches whose results need no cell lists)
+	uint32_t reserved;
 };
 
 // byte offsets inside a wave's scratch region
@@ -1139,6 +1141,20 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		uint32_t offset = h[256];
 		uint32_t row = sIdx * W + (W - 1);
 		out.start_node = node; out.start_offset = offset; out.start_row = row;
+		// node runs instead of moves (L.emit_runs): a run is opened at the first cell met in a node (its last cell on the read) once
+		// the trace is below the rows that do not count, and written out with its first cell when the path leaves the node
+		bool tracing = true;
+		const bool emitRuns = L.emit_runs != 0;
+		const uint32_t traceRows = L.jobs[st.job].trace_rows;
+		const uint32_t capRunWords = (L.cap_moves + 3) / 4 + 8;
+		uint32_t nRuns = 0, runLastOff = offset, runLastRow = row;
+		bool started = row < traceRows;
+		auto emitRun = [&](uint32_t n, uint32_t firstOff, uint32_t firstRow) {
+			if (5 * (nRuns + 1) > capRunWords) { status = GA_CAP_TRACE; tracing = false; return; }
+			uint32_t* d = m.moves + (uint64_t)(5 * nRuns) * 64;
+			d[0] = n; d[64] = firstOff; d[128] = firstRow; d[192] = runLastOff; d[256] = runLastRow;
+			nRuns++;
+		};
 		uint64_t e[4];
 		auto loadEq = [&](uint32_t sl) { const uint64_t* q = st.eq + (uint64_t)sl * 5; e[0] = q[0]; e[1] = q[1]; e[2] = q[2]; e[3] = q[3]; };
 		loadEq(sIdx);
@@ -1169,7 +1185,6 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		uint64_t firstCol = 0;
 		uint64_t wbases = 0;                          // the graph bases of the window's columns, 2 bits each from wLo up
 		uint32_t wLo = 1, wHi = 0;                    // columns of `node` (in slice sIdx) the window holds: [wLo, wHi], empty when wLo > wHi
-		bool tracing = true;
 		auto winRead = [&](uint32_t o, Col& c) {
 			const int at = tWIN + (int)(o - wLo) * 5;
 			c.vp = ((uint64_t)l.rd(at + 1) << 32) | l.rd(at);
@@ -1177,6 +1192,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			c.before = (int)l.rd(at + 4);
 		};
 		auto putMove = [&](int res, int via) {
+			if (emitRuns) return;
 			const uint32_t code = res == 1 ? GA_MOVE_LEFT : res == 2 ? GA_MOVE_DIAG : GA_MOVE_UP;
 			pack |= (code | (res == 3 ? 0u : ((uint32_t)via << 2))) << (8 * (len & 3));
 			if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * 64] = pack; pack = 0; }
@@ -1282,7 +1298,15 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					q0.vp = colMove ? q1.vp : q0.vp; q0.vn = colMove ? q1.vn : q0.vn; q0.before = colMove ? q1.before : q0.before;
 					q1.vp = colMove ? q2.vp : q1.vp; q1.vn = colMove ? q2.vn : q1.vn; q1.before = colMove ? q2.before : q1.before;
 					winRead(((offset >= wLo + 2) & (offset <= wHi)) ? offset - 2 : wLo, q2);
-					if (ok) putMove(left ? 1 : diag ? 2 : 3, 0);
+					if (emitRuns)
+					{
+						// (the first cell below the rows that do not count opens the first run)
+						const bool begin = ok & !started & (row < traceRows);
+						runLastOff = begin ? offset : runLastOff;
+						runLastRow = begin ? row : runLastRow;
+						started = started | begin;
+					}
+					else if (ok) putMove(left ? 1 : diag ? 2 : 3, 0);
 				}
 			}
 			{ const uint64_t t2 = lap_clock(); st.laps[0] += t2 - lapT; lapT = t2; }
@@ -1381,7 +1405,13 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					if (offset > wLo) winRead(offset - 1, q1);
 				}
 				const int here = col_value(q0.vp, q0.vn, q0.before, r);
-				if (row == 0 && node == st.seedNode && (here == 0 || here == 1)) { row = 0xffffffffu; tracing = false; continue; }     // free start (:500)
+				if (emitRuns && !started && row < traceRows) { started = true; runLastOff = offset; runLastRow = row; }
+				if (row == 0 && node == st.seedNode && (here == 0 || here == 1))                                                      // free start (:500)
+				{
+					if (emitRuns && started) emitRun(node, offset, row);
+					row = 0xffffffffu; tracing = false; continue;
+				}
+				const uint32_t rowBefore = row;
 				const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
 				const bool match = ((e[base] >> r) & 1) != 0;
 				int res = 0, via = 0;
@@ -1447,8 +1477,22 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					res = 3;
 				}
 				// put the move away (the step onto the row before the first one is not part of the trace, :949-950)
-				if (row == 0xffffffffu) { tracing = false; continue; }
+				if (row == 0xffffffffu)
+				{
+					if (emitRuns && started) emitRun(curNode, curOffset, rowBefore);     // the trace ends in the cell the step left
+					tracing = false; continue;
+				}
 				putMove(res, via);
+				if (emitRuns)
+				{
+					if (curOffset == 0 && res != 3 && node != curNode)
+					{
+						// (a self loop stays in its run, as consecutive cells of one node do in traceToAlignment :817-821)
+						if (started) { emitRun(curNode, curOffset, rowBefore); if (!tracing) continue; }
+						runLastOff = offset; runLastRow = row;
+					}
+					if (!started && row < traceRows) { started = true; runLastOff = offset; runLastRow = row; }
+				}
 				const uint64_t g1 = lap_clock();
 				const bool changed = res >= 2 && r == 0;                                // stepped into the slice above
 				if (changed)
@@ -1556,12 +1600,12 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		}
 #undef GAL_ANY
 		{ const uint64_t t2 = lap_clock(); st.laps[1] += t2 - lapT; lapT = t2; }
-		if (len & 3) m.moves[(uint64_t)(len >> 2) * 64] = pack;
+		if (!emitRuns && (len & 3)) m.moves[(uint64_t)(len >> 2) * 64] = pack;
 		st.laps[3] = lap_clock();
-		// hand the moves over: claim `len` bytes (rounded to words) of the pool and copy them
+		// hand the moves (or runs) over: claim their bytes (rounded to words) of the pool and copy them
 		if (status == GA_OK)
 		{
-			const uint32_t words = (len + 3) / 4;
+			const uint32_t words = emitRuns ? 5 * nRuns : (len + 3) / 4;
 #ifdef GA_EMULATE
 			const uint64_t at = *L.trace_top; *L.trace_top += (uint64_t)words * 4;
 #else
@@ -1580,7 +1624,8 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					for (int i = 0; i < 8; i++) if (k + (uint32_t)i < words) dst[k + (uint32_t)i] = a[i];
 				}
 				out.trace_off = at;
-				out.trace_len = len;
+				out.trace_len = emitRuns ? nRuns : len;
+				out.reserved3 = emitRuns ? 1u : 0u;
 				out.n_node_steps = nodeSteps;
 			}
 		}

@@ -48,6 +48,8 @@ struct GaJob {
 	uint64_t rows_off;     // offset of this job's row codes in the rows buffer
 	uint32_t n_rows;       // padded to a multiple of 64
 	uint32_t seed_node;    // graph node index the extension starts in
+	uint32_t trace_rows;   // rows of the trace that count: cells at rows >= this are dropped from its end (GraphAligner.h:3051-3055, 3069-3073)
+	uint32_t reserved;
 };
 
 struct GaJobOut {
@@ -61,7 +63,8 @@ struct GaJobOut {
 	uint64_t trace_off;    // byte offset of this job's moves inside the trace pool
 	uint32_t start_node, start_offset, start_row, reserved2;   // where the traceback starts (last kept slice, last row)
 	uint32_t n_node_steps;  // moves that left a node through its first column: the path has at most this many + 1 node runs
-	uint32_t reserved3;
+	uint32_t reserved3;     // 1: the job's bytes in the trace pool are node runs (5 words each: node, first offset, first row, last offset,
+	                        // last row; from the read's end to its start; trace_len = their number) instead of one byte per move
 	uint64_t stamps[8];    // diagnostic builds only (GA_STAMPS): shader cycles per phase; zero otherwise
 };
 

@@ -170,7 +170,8 @@ typedef struct ga_batch_stats {
 	double main_kernel_ms;       /* HIP-event time of the first pass alone (the lanes = reads kernel over all jobs) */
 	int32_t main_variant;        /* > 0: lanes = reads kernel, band nodes per lane * 1000 + record block * 10 + (1 when 32 lanes per wave);
 	                                < 0: wave-per-read kernel with that many band nodes in LDS */
-	int32_t reserved;
+	int32_t reserved;            /* 1: the batch's results need no cell lists (no GA_F_TRACE, one seed at the first base of every read, IUPAC
+	                                characters only) and the first-pass kernel handed back node runs instead of one byte per move */
 } ga_batch_stats_t;
 int ga_batch_stats(const ga_batch_t* b, ga_batch_stats_t* out);
 

@@ -71,6 +71,7 @@ struct EmulBatch : GaBackendBatch
 		L.traces = pool.data(); L.trace_top = &poolTop; L.trace_pool_cap = pool.size();
 		L.cap_cols = capCols; L.cap_rows = capRows; L.max_slices = cfg.max_slices; L.cap_moves = capMoves;
 		L.initial_bw = cfg.initial_bw; L.ramp_bw = cfg.ramp_bw;
+		L.emit_runs = cfg.emit_runs;
 		const WaveLayout lay = wave_layout<N>(capCols, capRows, cfg.max_slices, capMoves);
 		std::vector<uint8_t> scratch(lay.bytes + 256);
 		std::vector<uint32_t> lds((size_t)(Lay<N>::WORDS + kStageWordsLane) * 64);     // tables + the words of the staging image behind them

@@ -5,6 +5,7 @@ import numpy as np
 
 from graphaligner_amd import binding, synth
 import parity_common as pc
+import oracle_binding as ob
 
 
 def case_wave_primitives_on_hardware(lib_path=None):
@@ -271,6 +272,17 @@ def case_results_without_trace_items(lib_path=None):
         devs, oras = pc.run_both(graph.nodes, graph.edges, reads, seeds, 35, lib_path=lib_path, trace=False)
         for i, (d, o) in enumerate(zip(devs, oras)):
             pc.compare_read(d, dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "forward only, read %d" % i)
+        # ... and without the read that has a non-IUPAC character the whole batch qualifies for node runs instead of moves from the
+        # traceback (ga_batch_stats.reserved says so)
+        clean = [r for k, r in enumerate(reads) if k != 7]
+        cseeds = [s for k, s in enumerate(seeds) if k != 7]
+        gg = binding.Graph(graph.nodes, graph.edges, lib_path=lib_path)
+        batch = gg.prepare(clean, cseeds, 35, 0, flags=0)
+        batch.run()
+        assert batch.stats()["reserved"] == 1
+        og = ob.OracleGraph(graph.nodes, graph.edges)
+        for i, d in enumerate(batch.collect()):
+            pc.compare_read(d, dict(og.align(clean[i], [cseeds[i]], 35), trace=np.zeros((0, 7), dtype=np.int64)), "node runs, read %d" % i)
 
 
 def case_unknown_seed_node_reports_bad_seed(lib_path=None):
