@@ -288,7 +288,9 @@ struct DevBatch : GaBackendBatch
 		if (alloc(&L.trace_top, 2)) return GA_E_DEVICE;
 		uint64_t totalRows = 0;
 		for (auto& j : jobs) totalRows += j.n_rows;
-		L.trace_pool_cap = ((totalRows + totalRows / 2 + 256ull * jobs.size() + 4096) + 3) & ~3ull;
+		// one byte per move (a path makes at most ~1.5 moves per row), or 20 bytes per node run: room for a node change every 5 rows
+		// (a job that does not fit reports GA_CAP_TRACE and is rerun by the ladder, which writes moves)
+		L.trace_pool_cap = ((totalRows * (cfg.emit_runs ? 4 : 1) + totalRows / 2 + 256ull * jobs.size() + 4096) + 3) & ~3ull;
 		if (alloc(&L.traces, L.trace_pool_cap)) return GA_E_DEVICE;
 		HIP_OK(hipStreamSynchronize(stream));
 		return 0;
@@ -357,7 +359,8 @@ struct DevBatch : GaBackendBatch
 		P.max_slices = std::max<uint32_t>(maxRows / 64, 1);
 		P.cap_cols = std::min<uint32_t>(N * 256u, 0xff00u);
 		P.cap_rows = (P.max_slices * rowsPerSlice + 64 + 7u) & ~7u;               // (whole blocks of 8 rows: the block behind them is the spare one)
-		P.cap_moves = maxRows * 2 + 1024;
+		// (node runs are five words each and a path can change node at every row: the staging plane holds one run per row then)
+		P.cap_moves = cfg.emit_runs ? maxRows * 20 + 1024 : maxRows * 2 + 1024;
 		const gal::WaveLayout lay = gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves);
 		P.wave_bytes = lay.bytes;
 		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + LW * gal::kStageWords64 * 8;

@@ -168,7 +168,7 @@ struct LaneMem
 // what a lane carries from slice to slice
 struct LaneState
 {
-	uint32_t job, nRows, numSlices, seedNode;
+	uint32_t job, nRows, numSlices, seedNode, traceRows;
 	const uint64_t* eq;
 	int status;
 	bool live;                    // still in the slice loop
@@ -971,7 +971,7 @@ template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m
 	st.e0 = st.e1 = st.e2 = st.e3 = 0; st.rawAbove = 7;
 	st.sliceMin = 0; st.minSlot = 0; st.minOffset = 0;
 	st.nPushed = 0; st.nRun = 0; st.maxBandNodes = 0; st.kept = 0; st.nColumns = 0; st.rampUntil = 0; st.useRamp = false;
-	st.nRows = 0; st.numSlices = 0; st.seedNode = 0; st.eq = L.eq;
+	st.nRows = 0; st.numSlices = 0; st.seedNode = 0; st.traceRows = 0; st.eq = L.eq;
 	st.logCorrect = 0; st.logWrong = 0;
 	for (int i = 0; i < 8; i++) st.laps[i] = 0;
 	for (int i = 0; i < 5; i++) st.blaps[i] = 0;
@@ -980,6 +980,7 @@ template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m
 	st.nRows = job.n_rows;
 	st.numSlices = job.n_rows / W;
 	st.seedNode = job.seed_node;
+	st.traceRows = job.trace_rows;
 	st.eq = L.eq + (job.rows_off / W) * 5;
 	st.logCorrect = L.hmm->init_correct;
 	st.logWrong = L.hmm->init_wrong;
@@ -1145,7 +1146,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		// the trace is below the rows that do not count, and written out with its first cell when the path leaves the node
 		bool tracing = true;
 		const bool emitRuns = L.emit_runs != 0;
-		const uint32_t traceRows = L.jobs[st.job].trace_rows;
+		const uint32_t traceRows = st.traceRows;
 		const uint32_t capRunWords = (L.cap_moves + 3) / 4 + 8;
 		uint32_t nRuns = 0, runLastOff = offset, runLastRow = row;
 		bool started = row < traceRows;
