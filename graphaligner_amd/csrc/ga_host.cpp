@@ -808,7 +808,10 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	// read with one seed at its first base (one forward job: no backward part to mirror, no later seed to test against the cells
 	// of an earlier one, GraphAligner.h:423-429), no character whose TraceItem the reference would assert on
 	{
-		bool runs = (flags & GA_F_TRACE) == 0 && b->anyInvalidRow.load() == 0 && !(getenv("GA_RUNS") && atoi(getenv("GA_RUNS")) == 0);
+		// ... and a graph of long nodes (the shape the lanes = reads kernel is the first pass for): a path then changes node every few
+		// dozen rows and its runs are a fraction of its moves; on graphs chopped into short nodes moves are the smaller output
+		const double meanNode = g->nodeCount() > 2 ? (double)g->bases.size() / (double)(g->nodeCount() - 2) : 64.0;
+		bool runs = (flags & GA_F_TRACE) == 0 && b->anyInvalidRow.load() == 0 && meanNode >= 40 && !(getenv("GA_RUNS") && atoi(getenv("GA_RUNS")) == 0);
 		for (size_t i = 0; i < nReads && runs; i++) if (b->reads[i].nSeeds > 1) runs = false;
 		for (const SeedPlan& sp : b->seeds) if (sp.bwJob >= 0 || (sp.fwJob >= 0 && sp.pos != 0)) { runs = false; break; }
 		b->cfg.emit_runs = runs ? 1u : 0u;

@@ -1612,7 +1612,16 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 #else
 			const uint64_t at = atomicAdd((unsigned long long*)L.trace_top, (unsigned long long)words * 4);
 #endif
-			if (at + (uint64_t)words * 4 > L.trace_pool_cap) status = GA_CAP_TRACE;
+			if (at + (uint64_t)words * 4 > L.trace_pool_cap)
+			{
+				status = GA_CAP_TRACE;
+				// (give the claim back: the jobs after this one and the ladder's passes still find room)
+#ifdef GA_EMULATE
+				*L.trace_top -= (uint64_t)words * 4;
+#else
+				atomicAdd((unsigned long long*)L.trace_top, (unsigned long long)(0ull - (uint64_t)words * 4));
+#endif
+			}
 			else
 			{
 				uint32_t* dst = (uint32_t*)(L.traces + at);

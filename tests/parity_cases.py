@@ -273,13 +273,14 @@ def case_results_without_trace_items(lib_path=None):
         for i, (d, o) in enumerate(zip(devs, oras)):
             pc.compare_read(d, dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "forward only, read %d" % i)
         # ... and without the read that has a non-IUPAC character the whole batch qualifies for node runs instead of moves from the
-        # traceback (ga_batch_stats.reserved says so)
+        # traceback when the graph's nodes are long (ga_batch_stats.reserved says so)
         clean = [r for k, r in enumerate(reads) if k != 7]
         cseeds = [s for k, s in enumerate(seeds) if k != 7]
         gg = binding.Graph(graph.nodes, graph.edges, lib_path=lib_path)
         batch = gg.prepare(clean, cseeds, 35, 0, flags=0)
         batch.run()
-        assert batch.stats()["reserved"] == 1
+        # (node runs only on graphs of long nodes, mean >= 40 bp: the 64-bp chain here; the other two keep moves)
+        assert batch.stats()["reserved"] == (1 if all(len(seq) >= 40 for _, seq in graph.nodes[:-1]) else 0)
         og = ob.OracleGraph(graph.nodes, graph.edges)
         for i, d in enumerate(batch.collect()):
             pc.compare_read(d, dict(og.align(clean[i], [cseeds[i]], 35), trace=np.zeros((0, 7), dtype=np.int64)), "node runs, read %d" % i)
