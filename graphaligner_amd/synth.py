@@ -510,3 +510,41 @@ def simulate_reads_multi(mg, n_reads, length, seed=1, **kw):
         reads += r
         seeds += s
     return reads, seeds
+
+
+# ---- graphs whose bands reach 200 000 cells: the reference's sparse method and backtrace override ----------------
+class FanGraph:
+    """a head node, a stem, then `n_branches` long branches that start with the same `shared` bases and go their own ways
+    after them, each followed by a tail node.  When an alignment nears the stem's end the projected band holds every branch
+    whole (GraphAligner.h:1110-1159 works at node granularity), i.e. n_branches x branch_len cells: the case the reference hands
+    to calculateSliceAlternate (:2483).  (A seed ON the stem would make slice 0 sparse already: the initial slice scores every
+    column of the seed node 0, so its out-neighbours are always projected.)
+    Node ids: head 1, stem 2, branches 3 .. n+2, tails n+3 .. 2n+2."""
+
+    def __init__(self, head_len=300, stem_len=3000, n_branches=8, branch_len=30000, shared=150, tail_len=500, seed=1):
+        rng = np.random.default_rng(seed)
+        rnd = lambda n: _ALPHA[rng.integers(0, 4, size=n, dtype=np.uint8)]
+        self.head = rnd(head_len)
+        self.stem = rnd(stem_len)
+        prefix = rnd(shared)
+        self.branches = [np.concatenate([prefix, rnd(branch_len - shared)]) for _ in range(n_branches)]
+        self.tails = [rnd(tail_len) for _ in range(n_branches)]
+        self.nodes = [(1, self.head.tobytes().decode()), (2, self.stem.tobytes().decode())]
+        self.edges = [(1, False, 2, False)]
+        for k in range(n_branches):
+            self.nodes.append((3 + k, self.branches[k].tobytes().decode()))
+            self.edges.append((2, False, 3 + k, False))
+        for k in range(n_branches):
+            self.nodes.append((3 + n_branches + k, self.tails[k].tobytes().decode()))
+            self.edges.append((3 + k, False, 3 + n_branches + k, False))
+
+    def read_through(self, branch, stem_from, length, rng, sub=0.03, ins=0.03, dele=0.03, head_from=0):
+        """a read over the head (from `head_from`), the stem from `stem_from` bases in (0: all of it; otherwise the read jumps
+        there, which the aligner sees as one long deletion) and on into `branch`; seed = (head, 0, forward)"""
+        path = np.concatenate([self.head[head_from:], self.stem[stem_from:], self.branches[branch]])[:length]
+        return add_errors(path, sub, ins, dele, rng).tobytes().decode(), (1, 0, False)
+
+    def read_from_branch(self, branch, start, length, rng, sub=0.03, ins=0.03, dele=0.03):
+        """a read that starts inside a branch and crosses into its tail; seed on the branch node"""
+        path = np.concatenate([self.branches[branch][start:], self.tails[branch]])[:length]
+        return add_errors(path, sub, ins, dele, rng).tobytes().decode(), (3 + branch, 0, False)

@@ -359,6 +359,62 @@ Column stepColumn(u64 eq, Column c, bool upIn, bool upLeftIn, bool diagIn, bool 
 	return c;
 }
 
+// WordSlice::setValue (WordSlice.h:231-337): one cell of a column written by the sparse method.  A column is filled from
+// row 0 downwards; rows below the last one written are extrapolated with +1 per row.
+void setCell(Column& c, int row, int value)
+{
+	c.written |= 1ull << row;
+	if (!c.partial)
+	{
+		// first cell of the column: rows above it fall by one per row towards it (VN), rows below rise (:236-252)
+		c.partial = true;
+		c.before = value + row + 1;
+		if (row < W - 1) { c.vn = ~(kOnes << (row + 1)); c.vp = kOnes << (row + 1); }
+		else { c.vn = kOnes; c.vp = 0; }
+		c.rows = row;
+		c.end = value + W - row - 1;
+		return;
+	}
+	GAO_CHECK(c.rows < row);
+	if (c.rows == row - 1)
+	{
+		// the row right below the last one written (:254-280)
+		const int old = c.end - (W - c.rows - 1);
+		GAO_CHECK(old == columnValue(c, c.rows));
+		GAO_CHECK(value >= old - 1);
+		GAO_CHECK(value <= old + 1);
+		const u64 m = 1ull << row;
+		if (value == old - 1) { c.vn |= m; c.vp &= ~m; c.end -= 2; }
+		else if (value == old) { c.vn &= ~m; c.vp &= ~m; c.end -= 1; }
+		else { c.vp |= m; c.vn &= ~m; }
+		c.rows = row;
+		return;
+	}
+	// a gap: the rows between rise by one each, then every row down to `row` is capped by the run going up from the new cell (:281-336)
+	int sc[W];
+	sc[0] = c.before + bitAt(c.vp, 0) - bitAt(c.vn, 0);
+	for (int i = 1; i <= c.rows; i++) sc[i] = sc[i - 1] + bitAt(c.vp, i) - bitAt(c.vn, i);
+	for (int i = c.rows + 1; i <= row; i++) sc[i] = sc[i - 1] + 1;
+	for (int i = 0; i <= row; i++) sc[i] = std::min(sc[i], value + row - i);
+	GAO_CHECK(sc[0] >= c.before - 1);
+	GAO_CHECK(sc[0] <= c.before + 1);
+	auto put = [&](int i, int delta) {
+		const u64 m = 1ull << i;
+		if (delta == -1) { c.vp &= ~m; c.vn |= m; }
+		else if (delta == 0) { c.vp &= ~m; c.vn &= ~m; }
+		else { c.vp |= m; c.vn &= ~m; }
+	};
+	put(0, sc[0] - c.before);
+	for (int i = 1; i <= row; i++)
+	{
+		GAO_CHECK(sc[i] >= sc[i - 1] - 1);
+		GAO_CHECK(sc[i] <= sc[i - 1] + 1);
+		put(i, sc[i] - sc[i - 1]);
+	}
+	c.end = sc[row] + W - 1 - row;
+	c.rows = row;
+}
+
 // ===========================================================================================
 // HMM
 // ===========================================================================================
@@ -583,6 +639,7 @@ struct Slice                                                                 // 
 	size_t j = std::numeric_limits<size_t>::max();
 	size_t cellsProcessed = 0;
 	size_t numCells = 0;
+	bool sparse = false;                                                     // (bookkeeping for tests: which method filled the slice)
 	size_t estimatedMemory() const { return numCells * 4 + cells.nodeCount() * (sizeof(size_t) * 3 + sizeof(int)); }   // :136-139
 	Slice withCells(Store s) const
 	{
@@ -596,15 +653,25 @@ struct Slice                                                                 // 
 	Slice frozenFull() const { return withCells(cells.frozenFull()); }       // :153-165
 };
 
+typedef std::pair<size_t, size_t> Pos;                                       // (column, row)
+
+// BacktraceOverride (GraphAligner.h:167-354): the predecessor of every cell that can be reached backwards from an existing
+// end cell of a window of slices, worked out while the window's full slices are still in memory
+struct Override
+{
+	struct Item { bool end = false; bool sameRow = false; size_t previous = 0; Pos pos{0, 0}; };
+	size_t startj = 0, endj = 0;
+	std::vector<std::vector<Item>> items;                                    // per row of the window
+};
+
 struct Table                                                                 // DPTable (:355-367)
 {
 	std::vector<Slice> slices;
 	size_t samplingFrequency = 0;
 	std::vector<size_t> bandwidthPerSlice;
 	std::vector<Hmm> correctness;
+	std::vector<Override> overrides;
 };
-
-typedef std::pair<size_t, size_t> Pos;                                       // (column, row)
 
 struct NodeCalc { int minScore; std::vector<size_t> minIndex; size_t cellsProcessed; };
 
@@ -645,8 +712,9 @@ private:
 	const int initialBandwidth, rampBandwidth;
 	std::vector<SliceRecord>* record;
 	int recordDirection = 0;
+	bool countSparse = true;                                                 // false while slices are recomputed for the traceback
 	int lastRowMin = 0;                                                      // debugLastRowMinScore (:54-56)
-	size_t statColumns = 0, statSlices = 0;
+	size_t statColumns = 0, statSlices = 0, statSparse = 0, statOverrides = 0, statOverrideTraces = 0;
 
 	struct Split { size_t splitIndex = 0; Table forward, backward; size_t estimated() const { return (forward.bandwidthPerSlice.size() + backward.bandwidthPerSlice.size()) * W; } };
 	typedef std::pair<int, std::vector<Pos>> Trace;
@@ -678,9 +746,13 @@ private:
 	NodeCalc fillSlice(const std::string& seq, size_t j, Store& cur, const Store& prev, const std::vector<size_t>& order,
 	                   const std::vector<bool>& curBand, const std::vector<bool>& prevBand, std::vector<size_t>& compOf, WorkStack& work) const;
 	Slice extendAndFill(const std::string& seq, const Slice& previous, const std::vector<bool>& prevBand, std::vector<bool>& curBand,
-	                    std::vector<size_t>& compOf, WorkStack& work, std::vector<Span>& dense, int bandwidth);
+	                    std::vector<size_t>& compOf, WorkStack& work, std::vector<bool>& processed, std::vector<Span>& dense, int bandwidth);
+	NodeCalc fillSliceSparse(const std::string& seq, size_t startj, Store& cur, const Slice& previous, std::vector<bool>& processed, int bandwidth) const;
+	void finishSparseSlice(Slice& s, std::vector<bool>& curBand, int uninitialized, int bandwidth) const;
+	Override makeOverride(const std::string& seq, const Slice& previous, const std::vector<Slice>& window) const;
+	std::vector<Pos> overrideBacktrace(const Override& o, Pos start) const;
 	Table firstPass(const std::string& seq, const Slice& initial, size_t numSlices, size_t samplingFrequency, std::vector<Span>& dense);
-	std::vector<Slice> recompute(const std::string& seq, const Table& table, size_t startIndex, std::vector<Span>& dense);
+	std::vector<Slice> recompute(const std::string& seq, size_t overrideLastJ, const Table& table, size_t startIndex, std::vector<Span>& dense);
 	void trimWrongEnd(Table& t) const;
 	Slice seedSlice(size_t node) const;
 	Split splitAlign(const std::string& sequence, int bigraphNode, bool backwards, size_t pos, std::vector<Span>& dense);
@@ -1167,30 +1239,193 @@ NodeCalc Engine::fillSlice(const std::string& seq, size_t j, Store& cur, const S
 // band + fill for one slice (GraphAligner.h:2453-2521)
 // ------------------------------------------------------------------------------------------
 Slice Engine::extendAndFill(const std::string& seq, const Slice& previous, const std::vector<bool>& prevBand, std::vector<bool>& curBand,
-                            std::vector<size_t>& compOf, WorkStack& work, std::vector<Span>& dense, int bandwidth)
+                            std::vector<size_t>& compOf, WorkStack& work, std::vector<bool>& processed, std::vector<Span>& dense, int bandwidth)
 {
+	{
+		Slice s(&dense);
+		s.j = previous.j + W;
+		s.hmm = previous.hmm;
+		s.nodes = projectBand(previous.minScore, previous, bandwidth);
+		GAO_CHECK(s.nodes.size() > 0);
+		GAO_CHECK(seq.size() >= s.j + W);
+		size_t cells = 0;
+		for (size_t n : s.nodes) cells += g.nodeLen(n);
+		if (cells < kCutoff)                                                                       // :2483
+		{
+			for (size_t n : s.nodes)
+			{
+				s.cells.addNode(n, g.nodeLen(n));
+				curBand[n] = true;
+			}
+			NodeCalc r = fillSlice(seq, s.j, s.cells, previous.cells, s.nodes, curBand, prevBand, compOf, work);
+			s.cellsProcessed = r.cellsProcessed;
+			s.minIndex = r.minIndex;
+			s.minScore = r.minScore;
+			GAO_CHECK(s.minScore >= previous.minScore);                                            // :2469
+			s.hmm = s.hmm.next(s.minScore - previous.minScore, W);
+			s.numCells = cells;
+			return s;
+		}
+	}
+	// the band has 200 000 cells or more: cell by cell, only where the score stays within the bandwidth of the row's minimum (:2499-2520)
 	Slice s(&dense);
 	s.j = previous.j + W;
 	s.hmm = previous.hmm;
-	s.nodes = projectBand(previous.minScore, previous, bandwidth);
-	GAO_CHECK(s.nodes.size() > 0);
-	GAO_CHECK(seq.size() >= s.j + W);
-	size_t cells = 0;
-	for (size_t n : s.nodes) cells += g.nodeLen(n);
-	if (cells >= kCutoff) fail(UNSUPPORTED, "band >= 200000 cells needs the sparse method");
-	for (size_t n : s.nodes)
-	{
-		s.cells.addNode(n, g.nodeLen(n));
-		curBand[n] = true;
-	}
-	NodeCalc r = fillSlice(seq, s.j, s.cells, previous.cells, s.nodes, curBand, prevBand, compOf, work);
+	NodeCalc r = fillSliceSparse(seq, s.j, s.cells, previous, processed, bandwidth);
 	s.cellsProcessed = r.cellsProcessed;
 	s.minIndex = r.minIndex;
 	s.minScore = r.minScore;
-	GAO_CHECK(s.minScore >= previous.minScore);                                                // :2469
+	GAO_CHECK(s.minScore >= previous.minScore);
 	s.hmm = s.hmm.next(s.minScore - previous.minScore, W);
-	s.numCells = cells;
+	finishSparseSlice(s, curBand, (int)seq.size(), bandwidth);
+	s.sparse = true;
+	if (countSparse) statSparse++;
 	return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// the sparse method (calculateSliceAlternate, GraphAligner.h:2148-2329; setValue :2130-2146)
+// ------------------------------------------------------------------------------------------
+NodeCalc Engine::fillSliceSparse(const std::string& seq, size_t startj, Store& cur, const Slice& previous, std::vector<bool>& processed, int bandwidth) const
+{
+	typedef std::pair<size_t, size_t> Cell;                                                       // (node, column)
+	// With a bandwidth of 0 (slice 0 of a run without -B: the slice-0 quirk :2612) the reference indexes calculables[1] of a
+	// one-element vector (:2220, :2318): undefined behaviour there, reported as an assertion here.
+	if (bandwidth < 1) fail(ASSERTION, "sparse method with bandwidth 0: undefined behaviour in the reference (GraphAligner.h:2220)");
+	std::vector<std::vector<Cell>> now((size_t)bandwidth + 1), next((size_t)bandwidth + 1);
+	const int prevMin = previous.minScore;
+	const int uninitialized = (int)seq.size();
+	auto put = [&](std::vector<std::vector<Cell>>& q, long idx, size_t node, size_t column) {
+		GAO_CHECK(idx >= 0 && idx <= (long)bandwidth);                                             // (an out-of-range bucket would be undefined behaviour in the reference)
+		q[(size_t)idx].emplace_back(node, column);
+	};
+	auto matchAt = [&](size_t row, size_t column) { return charMatch(seq[row], g.base(column)); };
+	// cells of row startj reached from the previous slice's last row (:2163-2219), in the previous slice's container order
+	previous.cells.forEach([&](size_t node, const Span& sp) {
+		const size_t start = g.nodeBegin(node), len = sp.hi - sp.lo;
+		auto usable = [&](size_t i) { const Column c = previous.cells.get(sp.lo + i); return c.end < prevMin + bandwidth && c.endExists; };
+		auto endOf = [&](size_t i) { return previous.cells.get(sp.lo + i).end; };
+		if (startj == 0)
+		{
+			for (size_t i = 0; i < len; i++)
+			{
+				if (!usable(i)) continue;
+				put(now, endOf(i) - prevMin + (matchAt(startj, start + i) ? 0 : 1), node, start + i);
+			}
+		}
+		else
+		{
+			for (size_t i = 0; i + 1 < len; i++)
+			{
+				if (!usable(i)) continue;
+				GAO_CHECK(endOf(i) >= prevMin);
+				put(now, endOf(i) - prevMin + 1, node, start + i);
+				put(now, endOf(i) - prevMin + (matchAt(startj, start + i + 1) ? 0 : 1), node, start + i + 1);
+			}
+			if (usable(len - 1))
+			{
+				put(now, endOf(len - 1) - prevMin + 1, node, start + len - 1);
+				for (size_t nb : g.out[node])
+				{
+					const size_t u = g.nodeBegin(nb);
+					put(now, endOf(len - 1) - prevMin + (matchAt(startj, u) ? 0 : 1), nb, u);
+				}
+			}
+		}
+	});
+	GAO_CHECK(now[0].size() > 0 || now[1].size() > 0);                                             // :2220
+	std::vector<size_t> done;
+	size_t cellsProcessed = 0;
+	int minScore = prevMin;
+	for (int j = 0; j < W; j++)
+	{
+		const long plus = now[0].size() == 0 ? -1 : 0;                                             // the row's minimum is one above the last row's
+		for (int scoreplus = 0; scoreplus < bandwidth; scoreplus++)
+		{
+			// (the bucket can grow while it is walked: cells reached horizontally at the same score go to scoreplus + 1, never to this one)
+			for (size_t k = 0; k < now[(size_t)scoreplus].size(); k++)
+			{
+				const Cell cell = now[(size_t)scoreplus][k];
+				if (processed[cell.second]) continue;
+				cellsProcessed++;
+				processed[cell.second] = true;
+				done.push_back(cell.second);
+				const size_t nodeStart = g.nodeBegin(cell.first), nodeEnd = g.nodeEnd(cell.first);
+				GAO_CHECK(cell.second >= nodeStart);
+				GAO_CHECK(cell.second < nodeEnd);
+				if (!cur.has(cell.first))                                                          // setValue (:2130-2146): first touch of the node
+				{
+					cur.addNode(cell.first, g.nodeLen(cell.first));
+					const Span sp = cur.span(cell.first);
+					for (size_t i = sp.lo; i < sp.hi; i++)
+					{
+						Column c;
+						c.vp = 0; c.vn = 0; c.end = uninitialized; c.before = uninitialized; c.rows = 0; c.partial = false; c.beforeExists = false; c.endExists = true;
+						cur.at(i) = c;
+					}
+				}
+				Column& word = cur.at(cur.span(cell.first).lo + (cell.second - nodeStart));
+				setCell(word, j, minScore + scoreplus);
+				GAO_CHECK(columnValue(word, j) == minScore + scoreplus);                           // :2258
+				put(next, scoreplus + 1 + plus, cell.first, cell.second);
+				auto onward = [&](size_t node, size_t u) {
+					if (!processed[u]) put(now, scoreplus + 1, node, u);
+					if (j < W - 1) put(next, scoreplus + plus + (matchAt(startj + (size_t)j + 1, u) ? 0 : 1), node, u);
+				};
+				if (cell.second + 1 == nodeEnd) { for (size_t nb : g.out[cell.first]) onward(nb, g.nodeBegin(nb)); }
+				else onward(cell.first, cell.second + 1);
+			}
+		}
+		if (now[0].size() == 0) minScore++;
+		for (size_t c : done) { GAO_CHECK(processed[c]); processed[c] = false; }
+		done.clear();
+		if (j < W - 1)
+		{
+			std::swap(now, next);
+			for (auto& b : next) b.clear();
+		}
+	}
+	if (now[0].size() == 0) std::swap(now[0], now[1]);
+	GAO_CHECK(now[0].size() > 0);
+	NodeCalc res;
+	res.minScore = minScore;
+	for (const Cell& c : now[0]) res.minIndex.push_back(c.second);
+	res.cellsProcessed = cellsProcessed;
+	return res;
+}
+
+// finalizeAlternateSlice (GraphAligner.h:2523-2552)
+void Engine::finishSparseSlice(Slice& s, std::vector<bool>& curBand, int uninitialized, int bandwidth) const
+{
+	std::vector<std::pair<size_t, Span>> touched;
+	s.cells.forEach([&](size_t node, const Span& sp) { touched.emplace_back(node, sp); });
+	for (const auto& t : touched)
+	{
+		const size_t node = t.first;
+		const Span sp = t.second;
+		s.nodes.push_back(node);
+		GAO_CHECK(!curBand[node]);
+		curBand[node] = true;
+		int minScore = s.cells.at(sp.lo).end;
+		for (size_t i = sp.lo; i < sp.hi; i++)
+		{
+			Column& c = s.cells.at(i);
+			GAO_CHECK(c.rows <= W - 1);
+			GAO_CHECK(c.rows >= 0);
+			c.endExists = c.rows == W - 1;
+			c.rows = W;
+			c.partial = false;
+			minScore = std::min(minScore, c.end);
+		}
+		const int fill = minScore + (int)(sp.hi - sp.lo) + bandwidth + 1;
+		for (size_t i = sp.lo; i < sp.hi; i++)
+		{
+			Column& c = s.cells.at(i);
+			if (c.end == uninitialized) { c.end = fill; c.before = fill; }
+		}
+		s.numCells += sp.hi - sp.lo;
+		s.cells.setMin(node, minScore);
+	}
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1211,17 +1446,21 @@ Table Engine::firstPass(const std::string& seq, const Slice& initial, size_t num
 	Slice store = last;
 	GAO_CHECK(last.hmm.currentlyCorrect());
 	Slice rampSlice = last;
+	std::vector<bool> processed(g.bp(), false);
 	size_t rampRedoIndex = (size_t)-1;
 	size_t rampUntil = 0;
 	size_t lastProcessed = 0;
+	// the window of slices of >= 200 000 cells whose traceback is worked out while they are in memory (:2604-2606)
+	Slice overridePreslice = last;
+	std::vector<Slice> overrideTemps;
+	bool overriding = false;
 	for (size_t slice = 0; slice < numSlices; slice++)
 	{
 		int bandwidth = (rampUntil >= slice) ? rampBandwidth : initialBandwidth;                 // :2612 (slice 0 uses the ramp width)
 		lastProcessed = slice;
 		lastRowMin = last.minScore;
-		Slice fresh = extendAndFill(seq, last, prevBand, curBand, compOf, work, dense, bandwidth);
-		// (numCells >= cutoff cannot happen on the bit-vector path, so :2626-2629 and the
-		//  BacktraceOverride bookkeeping :2721-2764 are unreachable here)
+		Slice fresh = extendAndFill(seq, last, prevBand, curBand, compOf, work, processed, dense, bandwidth);
+		if (rampUntil == slice && fresh.numCells >= kCutoff) rampUntil++;                         // :2626-2629
 		if ((rampUntil == slice - 1 || (rampUntil < slice && fresh.hmm.currentlyCorrect() && fresh.hmm.falseFromCorrect)) && last.numCells < kCutoff)
 		{
 			rampSlice = last;
@@ -1235,7 +1474,7 @@ Table Engine::firstPass(const std::string& seq, const Slice& initial, size_t num
 			SliceRecord rec;
 			rec.direction = recordDirection; rec.j = fresh.j; rec.bandwidth = bandwidth; rec.nodes = fresh.nodes;
 			for (size_t n : fresh.nodes) { Span sp = fresh.cells.span(n); for (size_t i = sp.lo; i < sp.hi; i++) rec.columns.push_back(fresh.cells.get(i)); }
-			rec.minScore = fresh.minScore; rec.minIndex = fresh.minIndex;
+			rec.minScore = fresh.minScore; rec.minIndex = fresh.minIndex; rec.sparse = fresh.sparse;
 			record->push_back(std::move(rec));
 		}
 		if (!fresh.hmm.correctFromCorrect)
@@ -1256,7 +1495,41 @@ Table Engine::firstPass(const std::string& seq, const Slice& initial, size_t num
 			while (table.bandwidthPerSlice.size() > slice + 1) table.bandwidthPerSlice.pop_back();
 			while (table.correctness.size() > slice + 1) table.correctness.pop_back();
 			while (table.slices.size() > 1 && table.slices.back().j > slice * W) table.slices.pop_back();
+			if (overriding)                                                                        // :2673-2700
+			{
+				if (overridePreslice.j > last.j) { overriding = false; overrideTemps.clear(); }
+				else
+				{
+					// "shorten": the reference swaps an empty slice (j = SIZE_MAX) into the back of the list without popping it and
+					// tests the back's j again -- it never leaves that loop once it has entered it (:2690-2694)
+					if (overrideTemps.size() > 0 && overrideTemps.back().j > last.j)
+						fail(ASSERTION, "ramp redo inside a backtrace-override window: the reference does not terminate (GraphAligner.h:2690-2694)");
+				}
+			}
+			while (table.overrides.size() > 0 && table.overrides.back().endj > last.j) table.overrides.pop_back();
 			continue;
+		}
+		if (!overriding && fresh.numCells >= kCutoff && last.numCells < kCutoff)                  // :2721-2764
+		{
+			overridePreslice = last;
+			overriding = true;
+			overrideTemps.push_back(fresh.frozenFull());
+		}
+		else if (overriding)
+		{
+			if (fresh.numCells < kCutoff)
+			{
+				GAO_CHECK(overrideTemps.size() > 0);
+				GAO_CHECK(last.j == overrideTemps.back().j);
+				table.overrides.push_back(makeOverride(seq, overridePreslice, overrideTemps));
+				statOverrides++;
+				overriding = false;
+				while (table.slices.size() > 0 && table.slices.back().j >= table.overrides.back().startj && table.slices.back().j <= table.overrides.back().endj) table.slices.pop_back();
+				table.slices.push_back(last);
+				store = fresh.frozenEnds();
+				overrideTemps.clear();
+			}
+			else overrideTemps.push_back(fresh.frozenFull());
 		}
 		GAO_CHECK(table.bandwidthPerSlice.size() == slice);
 		table.bandwidthPerSlice.push_back(bandwidth);
@@ -1276,21 +1549,146 @@ Table Engine::firstPass(const std::string& seq, const Slice& initial, size_t num
 		fresh.cells.releaseDense();
 		std::swap(prevBand, curBand);
 	}
+	if (overriding)                                                                               // :2810-2825
+	{
+		GAO_CHECK(overrideTemps.size() > 0);
+		GAO_CHECK(last.j == overrideTemps.back().j);
+		table.overrides.push_back(makeOverride(seq, overridePreslice, overrideTemps));
+		statOverrides++;
+		overriding = false;
+		overrideTemps.clear();
+		while (table.slices.size() > 0 && table.slices.back().j >= table.overrides.back().startj && table.slices.back().j <= table.overrides.back().endj) table.slices.pop_back();
+	}
 	GAO_CHECK(table.bandwidthPerSlice.size() == lastProcessed + 1);                             // :2833
 	GAO_CHECK(table.slices.size() > 0);
 	for (size_t i = 0; i < table.slices.size(); i++) GAO_CHECK(i <= 1 || table.slices[i].j > table.slices[i - 1].j);
 	for (size_t i = 1; i < table.slices.size(); i++) GAO_CHECK(table.slices[i].minScore >= table.slices[i - 1].minScore);
+	for (size_t i = 0; i < table.overrides.size(); i++) GAO_CHECK(table.overrides[i].endj >= table.overrides[i].startj);
+	for (size_t i = 1; i < table.overrides.size(); i++) GAO_CHECK(table.overrides[i].startj > table.overrides[i - 1].endj);
 	return table;
+}
+
+// ------------------------------------------------------------------------------------------
+// BacktraceOverride (GraphAligner.h:167-354)
+// ------------------------------------------------------------------------------------------
+Override Engine::makeOverride(const std::string& seq, const Slice& previous, const std::vector<Slice>& window) const
+{
+	GAO_CHECK(window.size() > 0);
+	Override o;
+	o.startj = window[0].j;
+	o.endj = window.back().j;
+	GAO_CHECK(o.endj == o.startj + (window.size() - 1) * W);
+	const size_t nRows = W * window.size();
+	o.items.resize(nRows);
+	std::vector<std::unordered_map<size_t, size_t>> indexOf(nRows);
+	auto endExistsAt = [&](size_t row, size_t column) {
+		const Slice& s = window[row / W];
+		const size_t node = g.nodeOf(column);
+		GAO_CHECK(s.cells.has(node));
+		return s.cells.get(s.cells.span(node).lo + (column - g.nodeBegin(node))).endExists;
+	};
+	auto predecessorOf = [&](Pos pos, size_t row) {
+		const size_t si = row / W;
+		return si > 0 ? pickPredecessor(seq, window[si], pos, window[si - 1]) : pickPredecessor(seq, window[0], pos, previous);
+	};
+	// every cell reachable backwards from an existing end cell (addReachableRec :236-267; the recursion as a loop: a cell has one predecessor)
+	auto reach = [&](Pos pos, size_t row) {
+		while (true)
+		{
+			GAO_CHECK(row < nRows);
+			if (indexOf[row].count(pos.first) == 1) return;
+			const size_t size = indexOf[row].size();
+			indexOf[row][pos.first] = size;
+			if (row > 0 && row % W == W - 1 && !endExistsAt(row, pos.first)) return;
+			GAO_CHECK(row == pos.second - window[0].j);
+			const Pos pred = predecessorOf(pos, row);
+			GAO_CHECK(pred.second == pos.second || pred.second == pos.second - 1);
+			if (!(pred.second >= window[0].j && pred.second != (size_t)-1)) return;
+			pos = pred;
+			row = pred.second - window[0].j;
+		}
+	};
+	{
+		const Slice& bottom = window.back();
+		const size_t endRow = bottom.j + W - 1;
+		bottom.cells.forEach([&](size_t node, const Span& sp) {
+			const size_t start = g.nodeBegin(node);
+			for (size_t i = 0; i < sp.hi - sp.lo; i++) if (bottom.cells.get(sp.lo + i).endExists) reach(Pos{start + i, endRow}, nRows - 1);
+		});
+	}
+	for (size_t row = nRows; row-- > 0;)                                                          // makeTrace :293-341
+	{
+		o.items[row].resize(indexOf[row].size());
+		for (const auto& kv : indexOf[row])
+		{
+			const size_t w = kv.first, index = kv.second;
+			Override::Item& item = o.items[row][index];
+			const Pos pos{w, window[0].j + row};
+			item.pos = pos;
+			if (row % W == W - 1 && !endExistsAt(row, w)) { item.end = true; continue; }
+			const Pos pred = predecessorOf(pos, row);
+			if (pred.second == pos.second)
+			{
+				item.sameRow = true;
+				auto it = indexOf[row].find(pred.first);
+				if (it == indexOf[row].end()) fail(ASSERTION, "override: predecessor not indexed");    // unordered_map::at would throw
+				item.previous = it->second;
+			}
+			else
+			{
+				item.sameRow = false;
+				if (row != 0)
+				{
+					auto it = indexOf[row - 1].find(pred.first);
+					if (it == indexOf[row - 1].end()) fail(ASSERTION, "override: predecessor not indexed");
+					item.previous = it->second;
+				}
+				else item.previous = pred.first;
+			}
+		}
+		for (const auto& item : o.items[row]) GAO_CHECK(item.end || item.pos.first != 0);
+	}
+	return o;
+}
+
+// BacktraceOverride::GetBacktrace (:196-231): backwards from `start` (a cell of the window's last row) to the row above the window
+std::vector<Pos> Engine::overrideBacktrace(const Override& o, Pos start) const
+{
+	GAO_CHECK(o.items.size() > 0);
+	GAO_CHECK(o.items.size() % W == 0);
+	GAO_CHECK(o.items.back().size() > 0);
+	GAO_CHECK(o.items.back()[0].pos.second == start.second);
+	size_t index = (size_t)-1, row = o.items.size() - 1;
+	for (size_t i = 0; i < o.items.back().size(); i++) if (o.items.back()[i].pos == start) { index = i; break; }
+	GAO_CHECK(index != (size_t)-1);
+	std::vector<Pos> out;
+	while (true)
+	{
+		const Override::Item& cur = o.items[row][index];
+		GAO_CHECK(!cur.end);
+		out.push_back(cur.pos);
+		const size_t nextRow = cur.sameRow ? row : row - 1;
+		if (nextRow == (size_t)-1)
+		{
+			out.emplace_back(cur.previous, cur.pos.second - 1);
+			break;
+		}
+		index = cur.previous;
+		row = nextRow;
+	}
+	return out;
 }
 
 // ------------------------------------------------------------------------------------------
 // recompute the slices after checkpoint `startIndex`, keeping full bits (GraphAligner.h:2858-2943)
 // ------------------------------------------------------------------------------------------
-std::vector<Slice> Engine::recompute(const std::string& seq, const Table& table, size_t startIndex, std::vector<Span>& dense)
+std::vector<Slice> Engine::recompute(const std::string& seq, size_t overrideLastJ, const Table& table, size_t startIndex, std::vector<Span>& dense)
 {
 	GAO_CHECK(startIndex < table.slices.size());
 	size_t startSlice = (table.slices[startIndex].j + W) / W;
+	GAO_CHECK(overrideLastJ > startSlice * W);
 	size_t endSlice = startIndex == table.slices.size() - 1 ? table.bandwidthPerSlice.size() : (table.slices[startIndex + 1].j + W) / W;
+	if (endSlice * W >= overrideLastJ) endSlice = overrideLastJ / W;
 	GAO_CHECK(endSlice > startSlice);
 	GAO_CHECK(endSlice <= table.bandwidthPerSlice.size());
 	const Slice& initial = table.slices[startIndex];
@@ -1298,17 +1696,19 @@ std::vector<Slice> Engine::recompute(const std::string& seq, const Table& table,
 	std::vector<bool> prevBand(g.nodeCount(), false), curBand(g.nodeCount(), false);
 	std::vector<size_t> compOf(g.nodeCount(), std::numeric_limits<size_t>::max());
 	WorkStack work(g.nodeCount());
+	std::vector<bool> processed(g.bp(), false);
 	for (size_t n : initial.nodes) prevBand[n] = true;
 	lastRowMin = 0;
 	Slice last = initial.frozenEnds();
 	std::vector<SliceRecord>* keep = record;
 	record = nullptr;
+	countSparse = false;
 	size_t keepCols = statColumns, keepSlices = statSlices;
 	for (size_t slice = startSlice; slice < endSlice; slice++)
 	{
 		int bandwidth = (int)table.bandwidthPerSlice[slice];
 		lastRowMin = last.minScore;
-		Slice fresh = extendAndFill(seq, last, prevBand, curBand, compOf, work, dense, bandwidth);
+		Slice fresh = extendAndFill(seq, last, prevBand, curBand, compOf, work, processed, dense, bandwidth);
 		GAO_CHECK(out.size() == 0 || fresh.j == out.back().j + W);
 		out.push_back(fresh.frozenFull());
 		for (size_t n : last.nodes) { GAO_CHECK(prevBand[n]); prevBand[n] = false; }
@@ -1318,6 +1718,7 @@ std::vector<Slice> Engine::recompute(const std::string& seq, const Table& table,
 		std::swap(prevBand, curBand);
 	}
 	record = keep;
+	countSparse = true;
 	statColumns = keepCols; statSlices = keepSlices;
 	for (size_t i = 1; i < out.size(); i++) GAO_CHECK(out[i].minScore >= out[i - 1].minScore);
 	return out;
@@ -1449,6 +1850,12 @@ Engine::Trace Engine::traceTable(const std::string& seq, const Table& table, std
 	if (table.bandwidthPerSlice.size() == 0) return Trace{big, {}};
 	GAO_CHECK(table.samplingFrequency > 1);                                                    // :906 (reads shorter than 193 bp per direction fail here)
 	Trace result{0, {}};
+	size_t overrideIndex = (size_t)-1, lastOverrideStartJ = (size_t)-1, nextOverrideEndJ = (size_t)-1;
+	if (table.overrides.size() > 0)
+	{
+		overrideIndex = table.overrides.size() - 1;
+		nextOverrideEndJ = table.overrides.back().endj;
+	}
 	for (size_t i = table.slices.size(); i-- > 0;)
 	{
 		if ((table.slices[i].j + W) / W == table.bandwidthPerSlice.size())
@@ -1458,7 +1865,7 @@ Engine::Trace Engine::traceTable(const std::string& seq, const Table& table, std
 			result.second.emplace_back(table.slices.back().minIndex.back(), table.slices.back().j + W - 1);
 			continue;
 		}
-		auto part = recompute(seq, table, i, dense);
+		auto part = recompute(seq, lastOverrideStartJ, table, i, dense);
 		GAO_CHECK(part.size() > 0);
 		if (i == table.slices.size() - 1)
 		{
@@ -1470,8 +1877,18 @@ Engine::Trace Engine::traceTable(const std::string& seq, const Table& table, std
 		GAO_CHECK(inner.size() > 1);
 		result.second.insert(result.second.end(), inner.begin() + 1, inner.end());
 		auto across = traceBoundary(seq, part[0], table.slices[i], result.second.back().first);
-		GAO_CHECK(across.size() > 0);
 		result.second.insert(result.second.end(), across.begin(), across.end());
+		GAO_CHECK(across.size() > 0);
+		if (table.slices[i].j == nextOverrideEndJ)
+		{
+			// checkpoint i is the last slice of a window whose traceback was worked out in the first pass (:939-946)
+			auto through = overrideBacktrace(table.overrides[overrideIndex], result.second.back());
+			statOverrideTraces++;
+			result.second.insert(result.second.end(), through.begin() + 1, through.end());
+			lastOverrideStartJ = table.overrides[overrideIndex].startj;
+			overrideIndex--;
+			if (overrideIndex != (size_t)-1) nextOverrideEndJ = table.overrides[overrideIndex].endj;
+		}
 	}
 	GAO_CHECK(result.second.back().second == (size_t)-1);
 	result.second.pop_back();
@@ -1705,6 +2122,7 @@ AlignResult Engine::align(const std::string& seqId, const std::string& sequence,
 	}
 	res.columnsFirstPass = statColumns;
 	res.slicesFirstPass = statSlices;
+	res.sparseSlices = statSparse; res.overrideWindows = statOverrides; res.overrideTraces = statOverrideTraces;
 	const int big = std::numeric_limits<int>::max();
 	if (!have) return res;
 	if (bestTrace.first.first == big && bestTrace.second.first == big) return res;

@@ -36,7 +36,7 @@ using u64 = uint64_t;
 enum Status : int {
 	OK = 0,
 	ASSERTION = 1,       // the reference's always-on assert() would have thrown (ThreadReadAssertion.cpp:19-25)
-	UNSUPPORTED = 2,     // band >= 200000 cells: sparse method / BacktraceOverride not restated (GraphAligner.h:2148-2329,167-354)
+	UNSUPPORTED = 2,     // (unused since the sparse method and BacktraceOverride are restated: GraphAligner.h:2148-2329, 167-354)
 	BAD_SEED = 3,        // nodeLookup.at() would throw std::out_of_range (GraphAligner.h:423)
 };
 
@@ -83,12 +83,15 @@ struct Column {
 	bool partial = false;     // confirmedRows.partial
 	bool beforeExists = false;
 	bool endExists = true;
+	u64 written = 0;          // rows written by the sparse method (confirmedRows.exists, compiled into the reference only with
+	                          // EXTRACORRECTNESSASSERTIONS, WordSlice.h:233-235): kept for the cell-by-cell check in tests/, never read by the engine
 };
 
 int columnValue(const Column& c, int row);                                  // WordSlice.h:223-229
 Column mergeColumns(Column a, Column b);                                    // WordSlice.h:202-206, 361-421 (+423-510)
 Column stepColumn(u64 eq, Column left, bool upInBand, bool upLeftInBand, bool diagInBand,
                   bool prevRowEq, const Column& above, int lastRowMin);     // GraphAligner.h:1349-1427
+void setCell(Column& c, int row, int value);                                // WordSlice::setValue, WordSlice.h:231-337 (throws Failure)
 bool charMatch(char readChar, char graphChar);                              // GraphAligner.h:2039-2110 (throws Failure)
 std::string reverseComplement(const std::string& s);                        // CommonUtils.cpp:60-136 (throws Failure)
 
@@ -127,6 +130,9 @@ struct AlignResult {           // GraphAlignerWrapper.h:10-51
 	int32_t fwScore = 0, bwScore = 0;
 	size_t columnsFirstPass = 0;   // sum of DPSlice::numCells over first-pass slices (GraphAligner.h:2637)
 	size_t slicesFirstPass = 0;
+	size_t sparseSlices = 0;       // first-pass slices computed by the sparse method (GraphAligner.h:2499-2520), all seeds tried
+	size_t overrideWindows = 0;    // BacktraceOverride objects built (GraphAligner.h:2746, 2814), all seeds tried
+	size_t overrideTraces = 0;     // ... and walked by the traceback (GraphAligner.h:941)
 };
 
 // one first-pass slice, recorded for kernel-level golden vectors
@@ -136,6 +142,7 @@ struct SliceRecord {
 	std::vector<size_t> nodes; // processing-independent band order (DPSlice::nodes)
 	std::vector<Column> columns;   // concatenated in `nodes` order
 	int minScore; std::vector<size_t> minIndex;
+	bool sparse = false;       // computed by the sparse method
 };
 
 typedef std::tuple<int, size_t, bool> Seed;   // (bigraph node id, read position, reverse)

@@ -51,6 +51,7 @@ void gao_result_summary(void* rb, int64_t* out)
 	out[5] = (int64_t)r.queryPosition; out[6] = (int64_t)r.mappings.size(); out[7] = (int64_t)r.trace.size();
 	out[8] = (int64_t)r.fwTrace.size(); out[9] = (int64_t)r.bwTrace.size(); out[10] = r.fwScore; out[11] = r.bwScore;
 	out[12] = (int64_t)r.columnsFirstPass; out[13] = (int64_t)r.slicesFirstPass; out[14] = (int64_t)((ResultBox*)rb)->slices.size();
+	out[15] = (int64_t)r.sparseSlices; out[16] = (int64_t)r.overrideWindows; out[17] = (int64_t)r.overrideTraces;
 }
 const char* gao_result_message(void* rb) { return ((ResultBox*)rb)->r.message.c_str(); }
 // 6 values per mapping: node_id (digraph), is_reverse, offset, rank, from_length, to_length
@@ -109,6 +110,14 @@ void gao_slice_columns(void* rb, int i, uint64_t* vp, uint64_t* vn, int32_t* bef
 	}
 }
 
+// what the sparse method leaves per column: rows written, scoreEndExists; returns 1 when slice i was computed by the sparse method
+int gao_slice_sparse_info(void* rb, int i, uint64_t* written, uint8_t* endExists)
+{
+	const SliceRecord& s = ((ResultBox*)rb)->slices[i];
+	for (size_t k = 0; k < s.columns.size(); k++) { written[k] = s.columns[k].written; endExists[k] = s.columns[k].endExists; }
+	return s.sparse ? 1 : 0;
+}
+
 // ---- component-level entry points (pinned against oracle/_ref) ---------------------------------
 // column layout: vp, vn, end, before, rows, partial, beforeExists, endExists  (8 x int64, vp/vn bit-cast)
 static Column unpackColumn(const int64_t* c)
@@ -127,6 +136,22 @@ int gao_merge_columns(const int64_t* a, const int64_t* b, int64_t* out)
 	return guarded([&] { packColumn(mergeColumns(unpackColumn(a), unpackColumn(b)), out); });
 }
 int gao_column_value(const int64_t* c, int row) { return columnValue(unpackColumn(c), row); }
+// setCell chained from the sparse method's freshly touched column (same contract as ref_set_values in refparts.cpp)
+int gao_set_values(const int* rows, const int* values, int n, int uninitialized, int64_t* out)
+{
+	Column w;
+	w.vp = 0; w.vn = 0; w.end = uninitialized; w.before = uninitialized; w.rows = 0; w.partial = false; w.beforeExists = false; w.endExists = true;
+	int done = 0;
+	for (; done < n; done++)
+	{
+		Column next = w;
+		try { setCell(next, rows[done], values[done]); }
+		catch (const Failure&) { break; }
+		w = next;
+	}
+	packColumn(w, out);
+	return done;
+}
 int gao_step_column(uint64_t eq, const int64_t* left, int upIn, int upLeftIn, int diagIn, int prevRowEq, const int64_t* above, int64_t* out)
 {
 	return guarded([&] { packColumn(stepColumn(eq, unpackColumn(left), upIn, upLeftIn, diagIn, prevRowEq, unpackColumn(above), std::numeric_limits<int>::min()), out); });

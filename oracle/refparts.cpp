@@ -48,6 +48,25 @@ int ref_merge_columns(const int64_t* a, const int64_t* b, int64_t* out)
 // WordSlice::getValue (WordSlice.h:223-229)
 int ref_column_value(const int64_t* c, int row) { return unpack(c).getValue(row); }
 
+// WordSlice::setValue (WordSlice.h:231-337) applied, cell after cell, to a column initialised the way the sparse method's
+// first touch of a node does (GraphAligner.h:2137-2140): {0, 0, uninitialized, uninitialized, 0, false}, partial = false.
+// Returns the number of cells applied before an assertion (n when none failed); `out` is the column after the last good one.
+int ref_set_values(const int* rows, const int* values, int n, int uninitialized, int64_t* out)
+{
+	RefWord w {0, 0, uninitialized, uninitialized, 0, false};
+	w.confirmedRows.partial = false;
+	int done = 0;
+	for (; done < n; done++)
+	{
+		RefWord next = w;
+		try { next.setValue(rows[done], values[done]); }
+		catch (const ThreadReadAssertion::AssertionFailure&) { break; }
+		w = next;
+	}
+	pack(w, out);
+	return done;
+}
+
 // AlignmentCorrectnessEstimationState::NextState chained from the default state
 void ref_hmm_chain(const int* mismatches, int n, double* correct, double* wrong, uint8_t* flags)
 {

@@ -156,3 +156,81 @@ def check_slice(g, part, prev_rec, rec, padded_len):
             w, r = np.argwhere(got != sc)[0]
             raise AssertionError("slice j=%d node %d column %d row %d: oracle %d, cell-by-cell %d" % (j, n, w, j - 1 + r, got[w, r], sc[w, r]))
     return sum(len(g.seq[n]) for n in band) * 65
+
+
+# ---- slices computed by the sparse method ----------------------------------------------------------------------------
+def _scores_of(rec, cols):
+    """(len(cols) x 64) scores of rows j .. j+63 of the given columns of a recorded slice"""
+    vp = rec["vp"][cols][:, None] >> np.arange(64, dtype=np.uint64)[None, :] & np.uint64(1)
+    vn = rec["vn"][cols][:, None] >> np.arange(64, dtype=np.uint64)[None, :] & np.uint64(1)
+    return rec["before"][cols].astype(np.int64)[:, None] + np.cumsum(vp.astype(np.int64) - vn.astype(np.int64), axis=1)
+
+
+def check_sparse_slice(g, part, prev_rec, rec, padded_len):
+    """every cell the sparse method wrote (calculateSliceAlternate, GraphAligner.h:2148-2329) against the rule the reference's own
+    (stale) checker verifySliceAlternate spells out (:1681-1747): an existing cell equals min(above + 1, left + 1, diagonal +
+    mismatch), where a neighbour that does not exist counts as the read's length; a cell exists when the method wrote it
+    (confirmedRows.exists), a cell of the previous slice's last row when its scoreEndExists is set; at a node's first column
+    "left" and "diagonal" are the minima over the in-neighbours' last columns.  (:1720 reads the previous slice's value at a node's
+    first column without asking whether it exists; the method itself only starts from existing cells, :2170-2201, so existence is
+    asked for here as everywhere else.)  Returns the number of cells checked."""
+    j = rec["j"]
+    rows = part[j:j + 64]
+    big = padded_len
+    band = [int(n) for n in rec["nodes"]]
+    ccol = _node_columns(g, band)
+    if prev_rec.get("initial"):
+        prev_nodes = {prev_rec["node"]: (np.zeros(len(g.seq[prev_rec["node"]]), dtype=np.int64), np.ones(len(g.seq[prev_rec["node"]]), dtype=bool))}
+    else:
+        pcol = _node_columns(g, [int(n) for n in prev_rec["nodes"]])
+        prev_nodes = {n: (prev_rec["end"][c:c + len(g.seq[n])].astype(np.int64), prev_rec["end_exists"][c:c + len(g.seq[n])].astype(bool)) for n, c in pcol.items()}
+
+    def prev_last_row(n, offs):
+        """previous slice's row j-1 at the given offsets of node n, `big` where the cell does not exist"""
+        if n not in prev_nodes:
+            return np.full(len(offs), big, dtype=np.int64)
+        end, ex = prev_nodes[n]
+        return np.where(ex[offs], end[offs], big)
+
+    def cur_rows(n, offs):
+        """(len(offs) x 64) values of this slice at the given offsets of node n, `big` where the cell was not written"""
+        if n not in ccol:
+            return np.full((len(offs), 64), big, dtype=np.int64)
+        cols = ccol[n] + np.asarray(offs, dtype=np.int64)
+        wr = (rec["written"][cols][:, None] >> np.arange(64, dtype=np.uint64)[None, :] & np.uint64(1)).astype(bool)
+        return np.where(wr, _scores_of(rec, cols), big)
+
+    checked = 0
+    for n in band:
+        L = len(g.seq[n])
+        wr_all = rec["written"][ccol[n]:ccol[n] + L]
+        offs = np.nonzero(wr_all)[0]
+        if len(offs) == 0:
+            continue
+        here = cur_rows(n, offs)
+        exists = here != big
+        row_sets = np.array([sum(1 << "ACGT".index(c) for c in _MATCH[ch.upper()]) for ch in rows], dtype=np.int64)
+        base_bit = np.array(["ACGT".index(g.seq[n][o]) for o in offs], dtype=np.int64)
+        mism = 1 - ((row_sets[None, :] >> base_bit[:, None]) & 1)
+        # the column to the left: the same node's, or the best of the in-neighbours' last columns
+        left = np.full((len(offs), 64), big, dtype=np.int64)
+        left_above = np.full(len(offs), big, dtype=np.int64)
+        inner = offs > 0
+        if inner.any():
+            left[inner] = cur_rows(n, offs[inner] - 1)
+            left_above[inner] = prev_last_row(n, offs[inner] - 1)
+        if (~inner).any():
+            for m in g.inn[n]:
+                last = len(g.seq[m]) - 1
+                left[~inner] = np.minimum(left[~inner], cur_rows(m, [last]))
+                left_above[~inner] = np.minimum(left_above[~inner], prev_last_row(m, np.array([last])))
+        above0 = prev_last_row(n, offs)
+        vert = np.concatenate([above0[:, None], here[:, :-1]], axis=1)
+        diag = np.concatenate([left_above[:, None], left[:, :-1]], axis=1)
+        rule = np.minimum(np.minimum(vert + 1, left + 1), diag + mism)
+        bad = exists & (here != rule)
+        if bad.any():
+            k, r = np.argwhere(bad)[0]
+            raise AssertionError("sparse slice j=%d node %d offset %d row %d: oracle %d, rule %d" % (j, n, offs[k], j + r, here[k, r], rule[k, r]))
+        checked += int(exists.sum())
+    return checked

@@ -54,8 +54,10 @@ def lib():
         L.gao_slice_nodes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gao_slice_minindex.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gao_slice_columns.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.gao_slice_sparse_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.gao_merge_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.gao_column_value.argtypes = [C.c_void_p, C.c_int]
+        L.gao_set_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.gao_step_column.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gao_hmm_chain.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gao_char_match.argtypes = [C.c_int, C.c_int]
@@ -72,6 +74,8 @@ def reflib():
         R = C.CDLL(REF_SO)
         R.ref_merge_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         R.ref_column_value.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(R, "ref_set_values"):
+            R.ref_set_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         R.ref_hmm_chain.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         R.ref_frozen_order.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
         R.ref_freeze_thaw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -151,10 +155,10 @@ class OracleGraph:
 
 
 def _unpack_result(L, r):
-    s = np.zeros(15, dtype=np.int64)
+    s = np.zeros(18, dtype=np.int64)
     L.gao_result_summary(r, _p(s))
     res = dict(status=int(s[0]), failed=bool(s[1]), score=int(s[2]), alignment_start=int(s[3]), alignment_end=int(s[4]),
-               query_position=int(s[5]), fw_score=int(s[10]), bw_score=int(s[11]), columns=int(s[12]), slices=int(s[13]),
+               query_position=int(s[5]), fw_score=int(s[10]), bw_score=int(s[11]), columns=int(s[12]), slices=int(s[13]), sparse_slices=int(s[15]), override_windows=int(s[16]), override_traces=int(s[17]),
                message=L.gao_result_message(r).decode())
     nm, nt, nf, nb, ns = int(s[6]), int(s[7]), int(s[8]), int(s[9]), int(s[14])
     m = np.zeros((nm, 6), dtype=np.int64)
@@ -187,7 +191,10 @@ def _unpack_result(L, r):
         L.gao_slice_nodes(r, i, _p(nodes))
         L.gao_slice_minindex(r, i, _p(mi))
         L.gao_slice_columns(r, i, _p(vp), _p(vn), _p(before), _p(end), _p(ex))
+        written = np.zeros(nc, dtype=np.uint64)
+        eex = np.zeros(nc, dtype=np.uint8)
+        sparse = L.gao_slice_sparse_info(r, i, _p(written), _p(eex))
         slices.append(dict(direction=int(info[0]), j=int(info[1]), bandwidth=int(info[2]), nodes=nodes, min_score=int(info[5]),
-                           min_index=mi, vp=vp, vn=vn, before=before, end=end, before_exists=ex))
+                           min_index=mi, vp=vp, vn=vn, before=before, end=end, before_exists=ex, sparse=bool(sparse), written=written, end_exists=eex))
     res["slice_records"] = slices
     return res

@@ -190,3 +190,39 @@ def test_work_stack_matches_reference_unique_queue():
         n1 = L.gao_work_stack(ob._p(ops), len(ops), universe, ob._p(o1))
         n2 = ref.ref_unique_queue(ob._p(ops), len(ops), universe, ob._p(o2))
         assert n1 == n2 and (o1[:n1] == o2[:n2]).all()
+
+
+def test_set_value_matches_reference():
+    """the sparse method's cell writes (WordSlice::setValue, WordSlice.h:231-337): chains of (row, value) with consecutive rows,
+    gaps and values that break the reference's own asserts -- same column after every chain, same place of the first assertion"""
+    rng = np.random.default_rng(11)
+    L = ob.lib()
+    n_full = n_cut = 0
+    for it in range(6000):
+        rows, values = [], []
+        r = int(rng.integers(0, 8))
+        v = int(rng.integers(0, 50))
+        style = it % 4
+        while r < 64:
+            rows.append(r)
+            values.append(v)
+            step = 1 if (style == 0 or rng.random() < 0.7) else int(rng.integers(2, 12))
+            r += step
+            if style == 3:
+                v += int(rng.integers(-3, 4))          # often outside what the column allows: the asserts must fire at the same cell
+            else:
+                v += int(rng.integers(-1, 2)) if step == 1 else int(rng.integers(-step, step + 1))
+        ra = np.array(rows, dtype=np.int32)
+        va = np.array(values, dtype=np.int32)
+        o1 = np.zeros(8, dtype=np.int64)
+        o2 = np.zeros(8, dtype=np.int64)
+        uninit = 10048
+        d2 = ref.ref_set_values(ob._p(ra), ob._p(va), len(rows), uninit, ob._p(o2))
+        d1 = L.gao_set_values(ob._p(ra), ob._p(va), len(rows), uninit, ob._p(o1))
+        assert d1 == d2, (rows, values, d1, d2)
+        assert (o1 == o2).all(), (rows, values, o1, o2)
+        if d2 == len(rows):
+            n_full += 1
+        else:
+            n_cut += 1
+    assert n_full > 1500 and n_cut > 500
