@@ -24,9 +24,9 @@ namespace {
 
 struct SlotLayout
 {
-	uint64_t endPrev, endCur, sliceOff, arena, trace, flags, ckpt, belowOff, bytes;
+	uint64_t endPrev, endCur, sliceOff, arena, trace, flags, ckpt, belowOff, sparse, ovr, bytes;
 };
-__host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxSlices, uint64_t arenaWords, uint32_t traceCap)
+__host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxSlices, uint64_t arenaWords, uint32_t traceCap, uint32_t sparseBw = 0)
 {
 	auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
 	SlotLayout l;
@@ -39,6 +39,9 @@ __host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxS
 	l.flags = at; at = up(at + maxSlices + 1);
 	l.ckpt = at; at = up(at + 4ull * (maxSlices + 2));
 	l.belowOff = at; at = up(at + 4ull * (maxSlices + 1));
+	// the variant that carries the sparse method: its tables (first, so that the host can clear them) and the override windows
+	l.sparse = at; if (sparseBw) at = up(at + gak::sparse_mem_bytes(sparseBw));
+	l.ovr = at; if (sparseBw) at = up(at + 8ull * (maxSlices + 2));
 	l.bytes = at;
 	return l;
 }
@@ -46,11 +49,11 @@ __host__ __device__ inline SlotLayout slotLayout(uint32_t capCols, uint32_t maxS
 #ifndef GA_WAVES_EU
 #define GA_WAVES_EU 4
 #endif
-template <int MAXN, bool GENERAL>
+template <int MAXN, bool GENERAL, bool SPARSE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GA_WAVES_EU, 8))) ga_extend_kernel(GaLaunch L)
 {
 	__shared__ gak::WaveState<MAXN> ws;
-	const SlotLayout lay = slotLayout(L.cap_cols, L.max_slices, L.arena_words, L.trace_cap);
+	const SlotLayout lay = slotLayout(L.cap_cols, L.max_slices, L.arena_words, L.trace_cap, SPARSE ? L.sparse_bw : 0u);
 	uint8_t* base = L.scratch + (uint64_t)blockIdx.x * L.slot_bytes;
 	gak::Slot slot;
 	slot.end_prev = (uint32_t*)(base + lay.endPrev);
@@ -61,12 +64,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GA_WAVE
 	slot.slice_flags = base + lay.flags;
 	slot.ckpt = (uint32_t*)(base + lay.ckpt);
 	slot.below_off = (uint32_t*)(base + lay.belowOff);
+	slot.sparse = SPARSE ? base + lay.sparse : nullptr;
+	slot.ovr = SPARSE ? (uint32_t*)(base + lay.ovr) : nullptr;
+	slot.sparse_max_bw = SPARSE ? L.sparse_bw : 0u;
 	while (true)
 	{
 		uint32_t k = gaw::wave_atomic_add(L.next_job, 1u);
 		if (k >= L.n_jobs) break;                      // every wave reaches this exit once the queue is drained
 		uint32_t job = L.job_list ? L.job_list[k] : k;
-		gak::run_job<MAXN, GENERAL>(L, ws, slot, job);
+		gak::run_job<MAXN, GENERAL, SPARSE>(L, ws, slot, job);
 		__syncthreads();
 	}
 }
@@ -414,10 +420,12 @@ struct DevBatch : GaBackendBatch
 		return rc;
 	}
 
-	template <int MAXN, bool GENERAL> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry, bool takeCapacity, bool takeGeneral)
+	template <int MAXN, bool GENERAL, bool SPARSE = false> int retryPass(uint32_t capCols, uint64_t arenaWordsPerSlice, uint32_t traceMul, uint32_t wavesPerCuRetry, bool takeCapacity, bool takeGeneral,
+	                                                                    uint64_t arenaWordsExtra = 0)
 	{
 		std::vector<uint32_t> again;
-		for (uint32_t i : orderHost) if ((takeCapacity && isCapacity(outs[i].status)) || (takeGeneral && needsGeneral(outs[i].status))) again.push_back(i);
+		for (uint32_t i : orderHost)
+			if ((takeCapacity && isCapacity(outs[i].status)) || (takeGeneral && needsGeneral(outs[i].status)) || (SPARSE && outs[i].status == GA_UNSUPPORTED_BAND)) again.push_back(i);
 		if (again.empty()) return 0;
 		if (ensureRows()) return GA_E_DEVICE;
 		for (uint32_t i : again) passOf[i] = (uint8_t)passNo;
@@ -429,8 +437,9 @@ struct DevBatch : GaBackendBatch
 		Rl.cap_cols = capCols;
 		Rl.trace_cap = maxRows * traceMul + 4096;
 		Rl.max_slices = std::max<uint32_t>(maxRows / 64, 1);
-		Rl.arena_words = 64 + (uint64_t)(maxRows / 64) * (gak::kSliceHdrWords + arenaWordsPerSlice);
-		SlotLayout lay = slotLayout(Rl.cap_cols, Rl.max_slices, Rl.arena_words, Rl.trace_cap);
+		Rl.arena_words = std::min<uint64_t>(64 + (uint64_t)(maxRows / 64) * (gak::kSliceHdrWords + arenaWordsPerSlice) + arenaWordsExtra, 0xfffffff0ull);
+		Rl.sparse_bw = SPARSE ? (uint32_t)std::max(std::max(L.initial_bw, L.ramp_bw), 1) : 0u;
+		SlotLayout lay = slotLayout(Rl.cap_cols, Rl.max_slices, Rl.arena_words, Rl.trace_cap, Rl.sparse_bw);
 		Rl.slot_bytes = lay.bytes;
 		const uint64_t fit = scratchBudget() / lay.bytes;
 		uint32_t rslots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)g->cus * wavesPerCuRetry, fit), again.size()));
@@ -445,8 +454,10 @@ struct DevBatch : GaBackendBatch
 		if (!rc)
 		{
 			hipMemsetAsync(Rl.next_job, 0, 16, stream);
+			// (the sparse method's tables are generation-stamped: they start from zero once per launch)
+			if (SPARSE) hipMemset2DAsync(scratch + lay.sparse, lay.bytes, 0, gak::sparse_mem_bytes(Rl.sparse_bw), rslots, stream);
 			hipEventRecord(evA, stream);
-			hipLaunchKernelGGL((ga_extend_kernel<MAXN, GENERAL>), dim3(rslots), dim3(64), 0, stream, Rl);
+			hipLaunchKernelGGL((ga_extend_kernel<MAXN, GENERAL, SPARSE>), dim3(rslots), dim3(64), 0, stream, Rl);
 			float ms = 0;
 			rc = afterPass(ms);
 			if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: wave-per-read pass <%d,%d>: %zu jobs on %u slots, %.2f ms\n", MAXN, (int)GENERAL, again.size(), rslots, ms);
@@ -513,6 +524,10 @@ struct DevBatch : GaBackendBatch
 		rc = retryPass<64, true>(8192, 3 * 64 + 5 * 4096, 4, 8, false, true);      // only what needs the extra paths: capacity misses go straight on
 		if (rc) return rc;
 		rc = retryPass<256, true>(65536, 3 * 256 + 5 * 8192, 6, 4, true, true);
+		if (rc) return rc;
+		// bands of 200 000 cells and more (the reference's sparse method and backtrace override, ga_sparse.h): a fallback, run for the
+		// jobs that met such a band, with room for every column of every node such a slice touches
+		rc = retryPass<256, true, true>(1u << 20, 3 * 256 + 5 * 20000, 8, 1, false, false, 48ull << 20);
 		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
 		return rc;
 	}

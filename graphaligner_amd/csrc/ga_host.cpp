@@ -1303,7 +1303,7 @@ const char* ga_status_string(int s)
 	{
 		case GA_S_OK: return "ok";
 		case GA_S_ASSERTION: return "reference assertion";
-		case GA_S_UNSUPPORTED_BAND: return "band >= 200000 bp (sparse method not built)";
+		case GA_S_UNSUPPORTED_BAND: return "band >= 200000 bp and no device memory for the pass that carries the sparse method";
 		case GA_S_BAD_SEED: return "seed node not in graph";
 		case GA_S_CAPACITY: return "device buffer capacity";
 		case GA_S_UNSUPPORTED_CYCLE: return "cyclic band left unresolved by the kernel ladder";

@@ -81,7 +81,8 @@ template <int MAXN> struct WaveState
 
 struct Slot
 {
-	uint32_t* end_prev;      // packed (scoreEnd << 2 | vpLast | vnLast << 1) per column of the previous slice
+	uint32_t* end_prev;      // per column of the previous slice: scoreEnd << 3 | scoreEndExists << 2 | VN bit 63 << 1 | VP bit 63 (the
+	                         // reference's TinySlice, NodeSlice.h:26-31; scoreEndExists is only ever false after a sparse slice, GraphAligner.h:2536)
 	uint32_t* end_cur;
 	uint32_t* arena;         // slice records
 	uint32_t* slice_off;     // [max_slices] word offset of each slice record
@@ -89,6 +90,9 @@ struct Slot
 	uint8_t* trace;          // [trace_cap] staging for the traceback moves of the current job
 	uint32_t* ckpt;          // [max_slices + 2] checkpoint records of the reference's DPTable (ramp bookkeeping, wide variants)
 	uint32_t* below_off;     // [max_slices + 1] record standing for slice s when the traceback crosses from slice s + 1
+	uint8_t* sparse;         // scratch of the sparse method (ga_sparse.h), only in the kernel variant that carries it; else nullptr
+	uint32_t* ovr;           // [2 * (max_slices + 1)] backtrace-override windows (first slice, last slice), same variant
+	uint32_t sparse_max_bw;  // the bandwidth the sparse scratch was laid out for
 };
 
 GA_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
@@ -615,7 +619,8 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		// --- row j-1 of column 0 (forceComponentZeroRow for a single acyclic node, :1916-1937) ---
 		const int inDeg = in_degree(g, ws, s);
 		const int pend0raw = read_lane(pendRawV, 0);
-		const int pend0 = inPrev ? (pend0raw >> 2) : INF;
+		const int pend0 = inPrev ? (pend0raw >> 3) : INF;
+		const bool pex0 = inPrev && ((pend0raw >> 2) & 1) != 0;                  // the cell above column 0 exists (scoreEndExists)
 		int zero0 = pend0;
 		bool hasIn = false;
 		for (int e = 0; e < inDeg; e++)
@@ -630,7 +635,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		const int base0 = read_lane(baseV, 0);
 		const VI eqLane0 = bit_extract(rowCode, base0);
 		const bool aboveEq0 = aboveAlways || (j > 0 && rawAbove == base0);
-		const bool exists0 = inPrev && pend0 == zero0;                           // scoreBeforeExists from :1989 (scoreEndExists is always true here)
+		const bool exists0 = inPrev && pend0 == zero0 && pex0;                   // scoreBeforeExists from :1989
 		VI T;
 		int before0;
 		bool existsFirst;
@@ -638,7 +643,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 		{
 			// source node (:1475-1499): a vertical run from the cell above
 			if (j == 0 && inPrev) { T = VI(pend0 + 1 - read_lane(eqLane0, 0)); before0 = pend0; existsFirst = true; }
-			else if (inPrev) { T = VI(pend0 + 1); before0 = pend0; existsFirst = true; }
+			else if (inPrev) { T = VI(pend0 + 1); before0 = pend0; existsFirst = pex0; }              // (:1333-1337)
 			else { T = VI((int)(nRows + 1)); before0 = (int)(nRows + 1); existsFirst = false; }
 		}
 		else
@@ -682,7 +687,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			}
 			bool reenter = inPrev && calc > pend0;                               // vertical re-entry (:1504-1509)
 			before0 = reenter ? pend0 : calc;
-			existsFirst = reenter ? true : exists0;
+			existsFirst = reenter ? pex0 : exists0;                              // mergable.scoreBeforeExists = oldSlice[0].scoreEndExists (:1507)
 			T = vmin(prefix_min(G), VI(before0 + 1));
 		}
 
@@ -705,14 +710,15 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			}
 			// ---- the row j-1 bookkeeping of the whole chunk, lanes = columns ----
 			const VB live = lane < n;
-			const VI pendV = inPrev ? select(live, pendRawV >> 2, VI(INF)) : VI(INF);
-			const VI above2own = (pendRawV >> 2) - (pendRawV & 1) + ((pendRawV >> 1) & 1);      // score at row j-2 of the own column
+			const VI pendV = inPrev ? select(live, pendRawV >> 3, VI(INF)) : VI(INF);
+			const VI pexV = (pendRawV >> 2) & 1;                                 // scoreEndExists of the cell above
+			const VI above2own = (pendRawV >> 3) - (pendRawV & 1) + ((pendRawV >> 1) & 1);      // score at row j-2 of the own column
 			const VI above2left = shr1(above2own, carryAbove2);
 			const VI aboveEqV = aboveAlways ? VI(1) : (j > 0 ? select(baseV == rawAbove, VI(1), VI(0)) : VI(0));
 			// zero row (:1939-1944): zero[w] = min(zero[w-1] + 1, pend[w])
 			const VI zeroIn = first ? select(lane == 0, VI(zero0), pendV) : pendV;
 			const VI zeroV = vmin(prefix_min(zeroIn - lane) + lane, first ? VI(INF) : lane + (carryZero + 1));
-			const VI existsWV = inPrev ? select(pendV == zeroV, VI(1), VI(0)) : VI(0);
+			const VI existsWV = inPrev ? select(pendV == zeroV, pexV, VI(0)) : VI(0);
 			const VI viaDiagV = select(existsWV != 0, above2left + 1 - aboveEqV, VI(INF));   // :1369
 			// scoreBeforeStart (:1361-1370, then re-entry :1541-1546): before[w] = min(before[w-1] + 1, viaDiag[w], pend[w])
 			const VI cIn = first ? select(lane == 0, VI(before0), vmin(pendV, viaDiagV)) : vmin(pendV, viaDiagV);
@@ -720,7 +726,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			const VI beforeLeft = shr1(beforeV, carryBefore);
 			const VI calcV = vmin(beforeLeft + 1, viaDiagV);
 			const VB reenterV = (calcV > pendV) && inPrev;
-			VI existsV = select(reenterV, VI(1), existsWV);                    // final scoreBeforeExists of every column of the chunk
+			VI existsV = select(reenterV, pexV, existsWV);                     // final scoreBeforeExists of every column of the chunk (:1544)
 			if (first) existsV = select(lane == 0, VI(existsFirst ? 1 : 0), existsV);
 			// One scalar per column steers the inner loop: the bit offset into rowCode2 = graph base, +4 when the
 			// column to the left has no existing cell above it (then lane 0 must not see a match, :1358).
@@ -782,7 +788,7 @@ GA_FN int fill_slice(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot& slot,
 			// ---- the chunk leaves as four coalesced stores (VP, VN 8 B; before, packed end 4 B) ----
 			const VU vpV = make_vu(accVpLo, accVpHi), vnV = make_vu(accVnLo, accVnHi);
 			const VI endV = beforeV + vpopc(vpV) - vpopc(vnV);                   // scoreEnd = scoreBeforeStart + popcount(VP) - popcount(VN)
-			const VI packedV = (endV << 2) | ((accVpHi >> 31) & 1) | (((accVnHi >> 31) & 1) << 1);
+			const VI packedV = (endV << 3) | 4 | ((accVpHi >> 31) & 1) | (((accVnHi >> 31) & 1) << 1);     // (a bit-vector column's end cell always exists)
 			store_lanes(rec.vp + outBase + w0, n, vpV);
 			store_lanes(rec.vn + outBase + w0, n, vnV);
 			store_lanes(rec.before + outBase + w0, n, beforeV);
@@ -1035,7 +1041,7 @@ GA_FN int zero_row_component(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 		const bool inPrev = ps >= 0;
 		const uint32_t* pend = slot.end_prev + (inPrev ? ws.pn_colBase[ps] : 0);
 		const uint32_t outBase = ws.cn_colBase[s];
-		int zero0 = inPrev ? (int)(pend[0] >> 2) : INF;
+		int zero0 = inPrev ? (int)(pend[0] >> 3) : INF;
 		const int inDeg = in_degree(g, ws, s);
 		for (int e = 0; e < inDeg; e++)
 		{
@@ -1054,7 +1060,7 @@ GA_FN int zero_row_component(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 			if (zero0 != INF)
 			{
 				const VB live = lane < n;
-				const VI pendV = inPrev ? select(live, load_lanes(pend + w0, n, 0) >> 2, VI(INF)) : VI(INF);
+				const VI pendV = inPrev ? select(live, load_lanes(pend + w0, n, 0) >> 3, VI(INF)) : VI(INF);
 				const VI zin = w0 == 0 ? select(lane == 0, VI(zero0), pendV) : pendV;
 				zeroV = vmin(prefix_min(zin - lane) + lane, w0 == 0 ? VI(INF) : lane + (carry + 1));
 				carry = read_lane(zeroV, n - 1);
@@ -1114,10 +1120,11 @@ GA_FN int zero_row_component(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 			const int n = (int)(len - w0 < (uint32_t)LANES ? len - w0 : (uint32_t)LANES);
 			const VI b = load_lanes(rec.before + outBase + w0, n, 0);
 			if (ballot((lane < n) && (b == INF))) return GA_ASSERTION;
-			const VI pendV = inPrev ? (load_lanes(pend + w0, n, 0) >> 2) : VI(-1);
+			const VI pendRaw = inPrev ? load_lanes(pend + w0, n, 0) : VI(-8);
+			const VI pendV = pendRaw >> 3;
 			store_lanes(rec.vp + outBase + w0, n, VU(~0ull));
 			store_lanes(rec.vn + outBase + w0, n, VU(0ull));
-			store_lanes(slot.end_cur + outBase + w0, n, select(pendV == b, VI(256), VI(0)));
+			store_lanes(slot.end_cur + outBase + w0, n, select((pendV == b) && ((pendRaw & 4) != 0), VI(256), VI(0)));      // scoreBeforeExists (:1989)
 			last = read_lane(b, n - 1);
 		}
 		if (GA_LANE0) ws.cn_lastBefore[s] = last;
@@ -1154,11 +1161,11 @@ GA_FN int fill_node_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot
 	auto verticalEntry = [&](GCol& c, uint32_t w) {
 		// re-entry from the cell above when that beats what came from the left (:1504-1509, 1541-1546)
 		if (!inPrev) return;
-		const int oEnd = (int)(pend[w] >> 2);
+		const int oEnd = (int)(pend[w] >> 3);
 		if (c.before > oEnd)
 		{
 			GCol src;
-			src.vp = ~0ull; src.vn = 0; src.before = oEnd; src.rows = W; src.partial = false; src.exists = true;
+			src.vp = ~0ull; src.vn = 0; src.before = oEnd; src.rows = W; src.partial = false; src.exists = (pend[w] & 4) != 0;
 			c = gcol_merge(c, src, lowMask, status);
 		}
 	};
@@ -1166,7 +1173,7 @@ GA_FN int fill_node_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot
 		// assertSliceCorrectness (:1437-1455)
 		const int end = gcol_end(c);
 		if (c.before < 0 || end < 0 || (c.vp & c.vn) != 0) status = GA_ASSERTION;
-		if (inPrev && c.before > (int)(pend[w] >> 2)) status = GA_ASSERTION;
+		if (inPrev && c.before > (int)(pend[w] >> 3)) status = GA_ASSERTION;
 		if (c.rows == W && (end < prevMin || c.before < prevMin)) status = GA_ASSERTION;
 	};
 
@@ -1191,9 +1198,9 @@ GA_FN int fill_node_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot
 		if (j == 0 && inPrev)
 		{
 			const uint64_t firstVp = (eqOf[base0] & 1) ? 0 : 1;
-			c.vp = (~0ull & ~1ull) | firstVp; c.before = (int)(pend[0] >> 2); c.exists = true;
+			c.vp = (~0ull & ~1ull) | firstVp; c.before = (int)(pend[0] >> 3); c.exists = true;
 		}
-		else if (inPrev) { c.vp = ~0ull; c.before = (int)(pend[0] >> 2); c.exists = true; }
+		else if (inPrev) { c.vp = ~0ull; c.before = (int)(pend[0] >> 3); c.exists = (pend[0] & 4) != 0; }
 		else { c.vp = ~0ull & ~1ull; c.before = (int)(nRows + 1); c.exists = false; }
 	}
 	else
@@ -1237,7 +1244,7 @@ GA_FN int fill_node_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slot
 		const bool e = was.exists;
 		const int leftBefore = c.before;
 		int aboveEnd = 0, aboveEnd2 = 0;
-		if (inPrev) { const uint32_t pr = pend[w - 1]; aboveEnd = (int)(pr >> 2); aboveEnd2 = aboveEnd - (int)(pr & 1) + (int)((pr >> 1) & 1); }
+		if (inPrev) { const uint32_t pr = pend[w - 1]; aboveEnd = (int)(pr >> 3); aboveEnd2 = aboveEnd - (int)(pr & 1) + (int)((pr >> 1) & 1); }
 		c = gcol_step(eqOf[base], c, e, e, c.exists, aboveEqAt(base), aboveEnd, aboveEnd2, status);
 		verticalEntry(c, w);
 		if (!(inPrev || c.before == (int)j || c.before == leftBefore + 1)) status = GA_ASSERTION;    // :1548
@@ -1318,7 +1325,7 @@ GA_FN int fill_slice_general(const GaDevGraph& g, WaveState<MAXN>& ws, const Slo
 			const VU vpV = load_lanes_u64(rec.vp + outBase + w0, n), vnV = load_lanes_u64(rec.vn + outBase + w0, n);
 			const VI beforeV = load_lanes(rec.before + outBase + w0, n, 0);
 			const VI endV = beforeV + vpopc(vpV) - vpopc(vnV);
-			const VI packedV = (endV << 2) | vpopc(vpV & VU(1ull << 63)) | (vpopc(vnV & VU(1ull << 63)) << 1);
+			const VI packedV = (endV << 3) | 4 | vpopc(vpV & VU(1ull << 63)) | (vpopc(vnV & VU(1ull << 63)) << 1);
 			store_lanes(slot.end_cur + outBase + w0, n, packedV);
 			vp = read_lane(vpV, n - 1); vn = read_lane(vnV, n - 1);
 			before = read_lane(beforeV, n - 1); end = read_lane(endV, n - 1);
@@ -1345,6 +1352,10 @@ GA_FN int stored_value(const SliceRec& r, const uint32_t* tabNodes, const uint32
 	return r.before[idx] + __builtin_popcountll(vp & mask) - __builtin_popcountll(vn & mask);
 }
 
+}  // namespace gak
+#include "ga_sparse.h"
+namespace gak {
+
 // ---- the whole job --------------------------------------------------------------------------------------------
 // Slice records carry everything needed to continue from them: the narrow variant only ever continues from
 // the slice it has just finished; the wide variants also go back to an earlier one (the ramp redo of
@@ -1352,10 +1363,11 @@ GA_FN int stored_value(const SliceRec& r, const uint32_t* tabNodes, const uint32
 // when a redo has left the reference's checkpoint list inconsistent with the slices it finally kept.
 constexpr uint32_t kSeedRecord = 0xffffffffu;      // "record" of the initial slice (the seed node at score 0, j = -64)
 
-template <int MAXN, bool GENERAL>
+template <int MAXN, bool GENERAL, bool SPARSE = false>
 GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, uint32_t jobIndex)
 {
 	constexpr bool kWide = GENERAL;             // cycles and ramp redos: compiled into the general variants only
+	constexpr bool kSparse = SPARSE && GENERAL; // bands of >= 200 000 cells (sparse method, backtrace override): the last variant of the ladder only
 	const GaDevGraph& g = L.graph;
 	const GaJob job = L.jobs[jobIndex];
 	const GaHmmTables& hmm = *L.hmm;
@@ -1384,7 +1396,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			ws.pn_len[0] = seedLen;
 			ws.pn_outDeg[0] = 255;          // the seed node's out-list is read from HBM once
 		}
-		for (uint32_t c = 0; c < seedLen; c += LANES) store_lanes(slot.end_prev + c, (int)(seedLen - c), VI(0));
+		for (uint32_t c = 0; c < seedLen; c += LANES) store_lanes(slot.end_prev + c, (int)(seedLen - c), VI(4));      // score 0, scoreEndExists
 		pn = 1; prevMin = 0; logCorrect = hmm.init_correct; logWrong = hmm.init_wrong;
 		wave_sync();
 	};
@@ -1412,7 +1424,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			const int k = (int)(nC - c);
 			const VU vpV = load_lanes_u64(r.vp + c, k), vnV = load_lanes_u64(r.vn + c, k);
 			const VI endV = load_lanes(r.before + c, k, 0) + vpopc(vpV) - vpopc(vnV);
-			store_lanes(slot.end_prev + c, k, (endV << 2) | vpopc(vpV & VU(1ull << 63)) | (vpopc(vnV & VU(1ull << 63)) << 1));
+			store_lanes(slot.end_prev + c, k, (endV << 3) | 4 | vpopc(vpV & VU(1ull << 63)) | (vpopc(vnV & VU(1ull << 63)) << 1));
 		}
 		pn = (int)nN; prevMin = (int)r.hdr[2];
 		union { double d; uint32_t w[2]; } a, b;
@@ -1422,7 +1434,10 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	};
 
 	// a seed node of >= 200 000 bp is the whole band of the second slice: the reference goes sparse there (GraphAligner.h:2483)
-	if (seedLen >= kCutoff) status = GA_UNSUPPORTED_BAND;
+	// (with the sparse method compiled in: slice 0 of such a seed runs at the ramp width, :2612; without one that is a bandwidth of 0 and
+	// undefined behaviour in the reference, reported as an assertion; with one, every column of the seed node is a cell of row 0 --
+	// more than this program's tables hold, reported as a capacity miss)
+	if (seedLen >= kCutoff) status = kSparse ? (L.ramp_bw < 1 ? GA_ASSERTION : GA_CAP_COLS) : GA_UNSUPPORTED_BAND;
 	else if (seedLen > L.cap_cols) status = GA_CAP_COLS;
 	if (status == GA_OK) loadSeedState();
 	VI rowNext = load_lanes(rows, W, 0);
@@ -1437,13 +1452,51 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	// ---- one slice from the loaded state: band, order, fill; the record is written at arenaTop (not yet claimed) ----
 	int cn = 0, sliceMin = 0;
 	uint64_t need = 0;
+	// what the slice just computed was: its cells (DPSlice::numCells) and, for a slice of the sparse method, what its frozen forms could not hold
+	uint32_t freshCells = 0;
+	bool freshSparse = false, freshEndsTooFar = false, freshBeforeTooFar = false;
 	auto runSlice = [&](uint32_t slice, int bandwidth) -> int {
 		uint32_t totalCols = 0;
 		cn = 0;
+		freshSparse = false; freshEndsTooFar = false; freshBeforeTooFar = false;
 		GA_LAP(0);
 		int st = project_band(g, ws, pn, prevMin, bandwidth, cn, totalCols);
 		GA_LAP(1);
+		if constexpr (kSparse)
+		{
+			if (st == GA_UNSUPPORTED_BAND)
+			{
+				// ---- the band has 200 000 cells or more: the sparse method (pickMethodAndExtendFill, :2499-2520) ----
+				wave_sync();
+				if ((uint32_t)bandwidth > slot.sparse_max_bw) return GA_CAP_HEAP;
+				const SparseMem sm = sparse_mem_at(slot.sparse, slot.sparse_max_bw);
+				const SparseResult sr = sparse_fill(g, ws, slot, sm, rows + (uint64_t)slice * W, job.n_rows, slice * W, pn, prevMin, bandwidth, cn);
+				rowNextSlice = 0xffffffffu;                                           // (the row codes were not taken from the prefetch)
+				if (sr.status != GA_OK) return sr.status;
+				if (sr.oddWord) return GA_CAP_COLS;                                   // (see SparseResult::oddWord: reported, never a different answer)
+				if (sr.minScore < prevMin) return GA_ASSERTION;                      // :2508
+				sliceMin = sr.minScore;
+				freshSparse = true; freshEndsTooFar = sr.endsTooFar; freshBeforeTooFar = sr.beforeTooFar;
+				freshCells = sr.numCells;
+				out.n_columns += sr.numCells;
+				out.max_band_nodes = out.max_band_nodes > (uint32_t)cn ? out.max_band_nodes : (uint32_t)cn;
+				need = 0;
+				if (sr.endsTooFar) return GA_OK;                                      // the slice cannot outlive this iteration (see the loop): no record
+				if (sr.numCells > L.cap_cols) return GA_CAP_COLS;
+				need = slice_words((uint32_t)cn, sr.numCells) + (sr.numCells + 3) / 4;
+				if (arenaTop + need > L.arena_words || arenaTop + need >= 0xffffffffull) return GA_CAP_ARENA;
+				SliceRec rec = slice_at(slot.arena, arenaTop, (uint32_t)cn, sr.numCells);
+				sparse_materialize(g, ws, slot, sm, rec, (uint8_t*)(rec.before + sr.numCells), cn, sr.nWords, bandwidth);
+				if (GA_LANE0)
+				{
+					rec.hdr[0] = (uint32_t)cn; rec.hdr[1] = sr.numCells; rec.hdr[2] = (uint32_t)sliceMin; rec.hdr[3] = (uint32_t)sr.minSlot; rec.hdr[4] = sr.minOffset; rec.hdr[5] = 0;
+					rec.hdr[11] = 1u | (sr.beforeTooFar ? 2u : 0u);
+				}
+				return GA_OK;
+			}
+		}
 		if (st != GA_OK) return st;
+		freshCells = totalCols;
 		if (totalCols > L.cap_cols) return GA_CAP_COLS;
 		wave_order();
 		load_topology(g, ws, pn, cn);
@@ -1494,6 +1547,7 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		if (GA_LANE0)
 		{
 			rec.hdr[0] = (uint32_t)cn; rec.hdr[1] = totalCols; rec.hdr[2] = (uint32_t)sliceMin; rec.hdr[3] = (uint32_t)minSlot; rec.hdr[4] = minOffset; rec.hdr[5] = 0;
+			rec.hdr[11] = 0;
 		}
 		out.n_columns += totalCols;
 		out.max_band_nodes = out.max_band_nodes > (uint32_t)cn ? out.max_band_nodes : (uint32_t)cn;
@@ -1528,6 +1582,33 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	uint32_t storeMem = 28, rampUntil = 0, rampRedoIndex = 0xffffffffu, nCkpt = 0;
 	bool redone = false;
 	auto recSlice = [&](uint32_t recOff) -> uint32_t { return recOff == kSeedRecord ? 0xffffffffu : slot.arena[recOff + 10]; };   // slice index of a record (-1 for the seed)
+	// DPSlice::j as the reference compares it: unsigned, the seed slice's -64 is the largest value there is
+	auto recJ = [&](uint32_t recOff) -> uint64_t { return recOff == kSeedRecord ? ~0ull - 63 : (uint64_t)slot.arena[recOff + 10] * W; };
+	// backtrace-override bookkeeping of getSqrtSlices (:2604-2606, 2721-2764, 2810-2825): the open window = slices ovFirst .. ovFirst + ovCount - 1
+	uint32_t lastNumCells = 0, ovPreRec = kSeedRecord, ovFirst = 0, ovCount = 0, nOv = 0;
+	bool overriding = false, anyOverride = false;
+	(void)recJ; (void)ovPreRec; (void)ovFirst; (void)ovCount; (void)nOv; (void)overriding; (void)anyOverride; (void)lastNumCells;
+	// what building the override of the open window checks (ga_sparse.h), then the window joins the list and the checkpoints inside it go
+	auto closeWindow = [&]() -> int {
+		if constexpr (kSparse)
+		{
+			if (ovCount == 0 || lastRec == kSeedRecord || recSlice(lastRec) != ovFirst + ovCount - 1) return GA_ASSERTION;   // assert(lastSlice.j == backtraceOverrideTemps.back().j)
+			wave_sync();
+			const SparseMem sm = sparse_mem_at(slot.sparse, slot.sparse_max_bw);
+			const int st = explore_override(g, ws, slot, sm, slot.slice_off, ovFirst, ovCount, ovPreRec == kSeedRecord ? 0u : ovPreRec, ovPreRec == kSeedRecord,
+			                                job.seed_node, rows, (int)job.n_rows);
+			if (st != GA_OK) return st;
+			if (GA_LANE0) { slot.ovr[2 * nOv] = ovFirst; slot.ovr[2 * nOv + 1] = ovFirst + ovCount - 1; }
+			nOv++;
+			anyOverride = true;
+			overriding = false;
+			const uint64_t startj = (uint64_t)ovFirst * W, endj = (uint64_t)(ovFirst + ovCount - 1) * W;
+			while (nCkpt > 0 && recJ(slot.ckpt[nCkpt - 1]) >= startj && recJ(slot.ckpt[nCkpt - 1]) <= endj) nCkpt--;
+			ovCount = 0;
+			wave_sync();
+		}
+		return GA_OK;
+	};
 	for (uint32_t slice = 0; slice < numSlices && status == GA_OK; slice++)
 	{
 		// slice 0 always runs at the ramp width because rampUntil(0) >= slice(0) (:2603,2612)
@@ -1546,11 +1627,12 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		const double newCorrect = (cc > fc ? cc : fc) + hmm.correct_mult[mism];
 		const double newWrong = (cf > ff ? cf : ff) + hmm.wrong_mult[mism];
 		bool currentlyCorrect = newCorrect > newWrong;
+		if constexpr (kSparse) { if (rampUntil == slice && freshCells >= kCutoff) rampUntil++; }      // :2626-2629
 		if constexpr (kWide)
 		{
-			if (rampPossible && ((slice > 0 && rampUntil == slice - 1) || (rampUntil < slice && currentlyCorrect && falseFromCorrect)))
+			if (rampPossible && ((slice > 0 && rampUntil == slice - 1) || (rampUntil < slice && currentlyCorrect && falseFromCorrect)) && (!kSparse || lastNumCells < kCutoff))
 			{
-				rampRec = lastRec;                                               // :2630-2634 (the band is always below the cutoff here)
+				rampRec = lastRec;                                               // :2630-2634
 				rampRedoIndex = slice - 1;
 			}
 		}
@@ -1570,10 +1652,44 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 				if (backRec == kSeedRecord) loadSeedState(); else loadRecordState(backRec);
 				nPushed = back + 1;                                              // bandwidthPerSlice / correctness shrink to back + 1 entries
 				while (nCkpt > 1 && slot.ckpt[nCkpt - 1] != kSeedRecord && recSlice(slot.ckpt[nCkpt - 1]) > back) nCkpt--;
+				if constexpr (kSparse)
+				{
+					lastNumCells = backRec == kSeedRecord ? 0u : slot.arena[backRec + 1];
+					if (overriding)                                              // :2673-2700
+					{
+						if (recJ(ovPreRec) > recJ(lastRec)) { overriding = false; ovCount = 0; }
+						// "shorten": the reference swaps an empty slice (j = SIZE_MAX) into the back of its list, does not pop it and tests the
+						// back's j again -- once entered, that loop never ends (:2690-2694).  Reported as an assertion.
+						else if (ovCount > 0 && (uint64_t)(ovFirst + ovCount - 1) * W > recJ(lastRec)) { status = GA_ASSERTION; break; }
+					}
+					while (nOv > 0 && (uint64_t)slot.ovr[2 * (nOv - 1) + 1] * W > recJ(lastRec)) nOv--;
+				}
 				redone = true;
 				slice = back;                                                    // the loop increment makes it back + 1
 				continue;
 			}
+		}
+		const uint32_t thisMem = freshCells * 4 + (uint32_t)cn * 28;             // estimatedMemory (:136-139)
+		bool closedWindow = false;
+		if constexpr (kSparse)
+		{
+			// ---- the slice is kept: what the reference now freezes of it, and the override window it opens, extends or closes (:2721-2764) ----
+			bool pushTemps = false, closing = false;
+			if (!overriding && freshCells >= kCutoff && lastNumCells < kCutoff) { ovPreRec = lastRec; overriding = true; ovFirst = slice; ovCount = 0; pushTemps = true; }
+			else if (overriding) { if (freshCells < kCutoff) closing = true; else pushTemps = true; }
+			// lastSlice = newSlice.getFrozenSqrtEndScores() always follows (:2805), getFrozenScores for a window's list (:2729, 2762): both assert
+			// that the slice's scores lie within 16 bits of their minimum (NodeSlice.h:344, 372) -- which a long node's untouched columns break
+			if (freshSparse && (freshEndsTooFar || (pushTemps && freshBeforeTooFar))) { status = GA_ASSERTION; break; }
+			if (closing)
+			{
+				status = closeWindow();
+				if (status != GA_OK) break;
+				if (GA_LANE0) slot.ckpt[nCkpt] = lastRec;                        // result.slices.push_back(lastSlice) (:2752)
+				nCkpt++;
+				closedWindow = true;
+				wave_order();
+			}
+			if (pushTemps) ovCount++;
 		}
 		if (GA_LANE0)
 		{
@@ -1583,16 +1699,16 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			hdr[5] = (uint32_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0) | (useRamp ? 4 : 0));
 			hdr[6] = a.w[0]; hdr[7] = a.w[1]; hdr[8] = b.w[0]; hdr[9] = b.w[1]; hdr[10] = slice;
 			slot.slice_off[slice] = thisRec;
-			slot.slice_flags[slice] = (uint8_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0) | (useRamp ? 4 : 0));
+			slot.slice_flags[slice] = (uint8_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0) | (useRamp ? 4 : 0) | ((freshSparse && freshBeforeTooFar) ? 16 : 0));
 		}
 		if (nPushed != slice) { status = GA_ASSERTION; break; }                  // :2768
 		nPushed++;
-		const uint32_t thisMem = slot.arena[arenaTop + 1] * 4 + (uint32_t)cn * 28;   // estimatedMemory (:136-139)
 		arenaTop += need;
 		logCorrect = newCorrect; logWrong = newWrong;
+		if (closedWindow) { storeRec = thisRec; storeMem = thisMem; }            // storeSlice = newSlice.getFrozenSqrtEndScores() (:2756)
 		if constexpr (kWide)
 		{
-			if (rampPossible)
+			if (rampPossible || kSparse)
 			{
 				// checkpoint = cheapest slice of each sqrt window (:2772-2786)
 				if (slice % sampling == 0)
@@ -1609,7 +1725,13 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			}
 		}
 		lastRec = thisRec;
+		lastNumCells = freshCells;
 		adoptSlice();
+	}
+	if constexpr (kSparse)
+	{
+		// a window still open when the slices end (:2810-2825); its checkpoints go, nothing is pushed
+		if (status == GA_OK && overriding) status = closeWindow();
 	}
 	out.n_run = nRun;
 	GA_LAP(0);
@@ -1636,54 +1758,91 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 	uint32_t startRec = kept > 0 ? slot.slice_off[kept - 1] : 0;
 	if constexpr (kWide)
 	{
-		if (status == GA_OK && redone)
+		const bool tableTouched = redone || (kSparse && anyOverride);             // (otherwise the checkpoint list is in order by construction)
+		if (status == GA_OK && tableTouched)
 		{
-			// the checks at the end of getSqrtSlices (:2833-2842) look at the whole checkpoint list, before the wrongly aligned tail
+			// the checks at the end of getSqrtSlices (:2833-2854) look at the whole checkpoint list, before the wrongly aligned tail
 			// is trimmed (removeWronglyAlignedEnd is the caller's next step, :3002,3018) and whether or not anything is kept
 			wave_sync();
 			if (nCkpt == 0) status = GA_ASSERTION;                                // :2834
 			for (uint32_t i = 1; i < nCkpt && status == GA_OK; i++)
 			{
 				const uint32_t a = slot.ckpt[i - 1], b = slot.ckpt[i];
-				if (i >= 2 && !(recSlice(b) > recSlice(a))) status = GA_ASSERTION;                 // :2835-2838
+				if (i >= 2 && !(recJ(b) > recJ(a))) status = GA_ASSERTION;                           // :2835-2838
 				const int ma = a == kSeedRecord ? 0 : (int)slot.arena[a + 2], mb = b == kSeedRecord ? 0 : (int)slot.arena[b + 2];
 				if (mb < ma) status = GA_ASSERTION;                                                // :2839-2842
 			}
+			if constexpr (kSparse)
+			{
+				for (uint32_t i = 1; i < nOv && status == GA_OK; i++) if (!(slot.ovr[2 * i] > slot.ovr[2 * (i - 1) + 1])) status = GA_ASSERTION;   // :2850-2853
+			}
 			if (status != GA_OK) out.n_valid = 0;
 		}
-		if (status == GA_OK && redone && kept > 0 && numSlices >= 4)
+		if (status == GA_OK && tableTouched && kept > 0 && numSlices >= 4)
 		{
 			wave_sync();
 			const auto firstPassColumns = out.n_columns;                          // the column-update count is the first pass's (cellsProcessed)
 			const auto firstPassNodes = out.max_band_nodes;
-			// trimmed checkpoints (:2566-2568)
-			while (status == GA_OK && nCkpt > 1 && slot.ckpt[nCkpt - 1] != kSeedRecord && recSlice(slot.ckpt[nCkpt - 1]) >= kept) nCkpt--;
+			// trimmed checkpoints (:2566-2568; the overrides are not trimmed)
+			while (status == GA_OK && nCkpt > 1 && recJ(slot.ckpt[nCkpt - 1]) >= (uint64_t)kept * W) nCkpt--;
 			for (uint32_t sIdx = 0; sIdx < kept; sIdx++) if (GA_LANE0) slot.below_off[sIdx] = slot.slice_off[sIdx];
 			wave_sync();
+			// getTraceFromTable's walk over the checkpoints, last to first (:917-947): between two of them the reference recomputes the slices
+			// (asserting what getSlicesFromTable asserts, freezing every recomputed slice), and where a checkpoint is the last slice of the
+			// next override window it follows that window's links instead and recomputes nothing of it
+			uint32_t usedLo = 0xffffffffu;                                        // lastBacktraceOverrideStartJ / 64
+			int ovIdx = (int)nOv - 1;
 			for (uint32_t i = nCkpt; i-- > 0 && status == GA_OK;)
 			{
 				const uint32_t ck = slot.ckpt[i];
 				const uint32_t ckSlice = recSlice(ck);                               // 0xffffffff for the seed
 				const uint32_t firstSlice = ckSlice + 1;                             // wraps to 0 for the seed
-				const uint32_t endSlice = i + 1 == nCkpt ? kept : recSlice(slot.ckpt[i + 1]) + 1;
+				uint32_t endSlice = i + 1 == nCkpt ? kept : recSlice(slot.ckpt[i + 1]) + 1;
 				if (ck != kSeedRecord && GA_LANE0) slot.below_off[ckSlice] = ck;
 				if (firstSlice == kept)
 				{
 					if (i + 1 != nCkpt) status = GA_ASSERTION;                       // :911
 					continue;
 				}
-				if (!(endSlice > firstSlice) || endSlice > kept) { status = GA_ASSERTION; break; }   // :2862-2866
-				const bool consistent = ck == kSeedRecord || ck == slot.slice_off[ckSlice];
-				if (consistent) continue;                                            // the recompute would reproduce the kept slices
-				loadRecordState(ck);
-				for (uint32_t sl = firstSlice; sl < endSlice && status == GA_OK; sl++)
+				if constexpr (kSparse)
 				{
-					const int bandwidth = (slot.slice_flags[sl] & 4) ? L.ramp_bw : L.initial_bw;
-					status = runSlice(sl, bandwidth);
+					if (!(usedLo > firstSlice)) { status = GA_ASSERTION; break; }     // assert(overrideLastJ > startSlice * 64) (:2862)
+					if (endSlice >= usedLo) endSlice = usedLo;                       // :2865
+				}
+				if (!(endSlice > firstSlice) || endSlice > kept) { status = GA_ASSERTION; break; }   // :2866-2867
+				if constexpr (kSparse)
+				{
+					// result.push_back(newSlice.getFrozenScores()) for every recomputed slice (:2908; NodeSlice.h:344)
+					wave_sync();
+					for (uint32_t sl = firstSlice; sl < endSlice; sl++) if (slot.slice_flags[sl] & 16) status = GA_ASSERTION;
 					if (status != GA_OK) break;
-					if (GA_LANE0) { slot.arena[arenaTop + 10] = sl; slot.slice_off[sl] = (uint32_t)arenaTop; if (sl + 1 < endSlice || i + 1 == nCkpt) slot.below_off[sl] = (uint32_t)arenaTop; }
-					arenaTop += need;
-					adoptSlice();
+				}
+				const bool consistent = ck == kSeedRecord || ck == slot.slice_off[ckSlice];
+				if (!consistent && redone)
+				{
+					// the recompute would NOT reproduce the kept slices: a checkpoint taken before a ramp redo
+					loadRecordState(ck);
+					for (uint32_t sl = firstSlice; sl < endSlice && status == GA_OK; sl++)
+					{
+						const int bandwidth = (slot.slice_flags[sl] & 4) ? L.ramp_bw : L.initial_bw;
+						status = runSlice(sl, bandwidth);
+						if (status != GA_OK) break;
+						if (freshSparse && (freshEndsTooFar || freshBeforeTooFar)) { status = GA_ASSERTION; break; }
+						if (GA_LANE0) { slot.arena[arenaTop + 10] = sl; slot.slice_off[sl] = (uint32_t)arenaTop; if (sl + 1 < endSlice || i + 1 == nCkpt) slot.below_off[sl] = (uint32_t)arenaTop; }
+						arenaTop += need;
+						adoptSlice();
+					}
+				}
+				if constexpr (kSparse)
+				{
+					if (status == GA_OK && ck != kSeedRecord && ovIdx >= 0 && ckSlice == slot.ovr[2 * ovIdx + 1])
+					{
+						// GetBacktrace through the window (:939-946): its slices are the first pass's; flag them for the traceback's row-63 rule
+						const uint32_t lo = slot.ovr[2 * ovIdx];
+						if (GA_LANE0) for (uint32_t sl = lo; sl <= ckSlice; sl++) slot.slice_flags[sl] |= 8;
+						usedLo = lo;
+						ovIdx--;
+					}
 				}
 			}
 			wave_sync();
@@ -1783,6 +1942,18 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 			if (len + LANES >= L.trace_cap) { status = GA_CAP_TRACE; break; }
 			int r = (int)(row - sIdx * W);
 			if (rowvSlice != sIdx) { rowv = load_lanes(rows + sIdx * W, W, 0); rowvSlice = sIdx; }
+			if constexpr (kSparse)
+			{
+				// inside an override window the reference follows precomputed links, and a cell of a slice's last row without an end
+				// score has none (BacktraceItem::end, :311-317; assert(!current.end) :211; the entry cell must be among them, :202-209)
+				if (r == W - 1 && (slot.slice_flags[sIdx] & 8))
+				{
+					const int sx = find_slot(curNodes, (int)nN, node);
+					if (sx < 0) { status = GA_ASSERTION; break; }
+					const uint8_t* ex = (const uint8_t*)(cur.before + cur.hdr[1]);
+					if (ex[curBase[sx] + offset] == 0) { status = GA_ASSERTION; break; }
+				}
+			}
 			// ---- make the current window cover this column (and its left neighbour when there is one) ----
 			bool covers = cw.valid && cw.slice == sIdx && cw.node == node && (int)offset >= cw.lo && (int)offset < cw.lo + cw.n && !((int)offset == cw.lo && offset > 0);
 			if (!covers)

@@ -6,7 +6,8 @@
 enum GaStatus : int32_t {
 	GA_OK = 0,
 	GA_ASSERTION = 1,          // an always-on assert() of the reference would have thrown for this read
-	GA_UNSUPPORTED_BAND = 2,   // band >= 200000 bp: the reference switches to its sparse method (GraphAligner.h:2483), not built here
+	GA_UNSUPPORTED_BAND = 2,   // band >= 200000 bp: the reference switches to its sparse method (GraphAligner.h:2483); internal: the job moves to the
+	                           // last kernel of the ladder, which carries that method (ga_sparse.h)
 	GA_BAD_SEED = 3,           // seed node id not in the graph (std::out_of_range in the reference, GraphAligner.h:423)
 	GA_CAP_NODES = 10,         // band holds more nodes than this kernel variant keeps in LDS -> rerun with the wide variant
 	GA_CAP_COLS = 11,          // band holds more columns than the slot's end-score buffers
@@ -91,6 +92,8 @@ struct GaLaunch {
 	uint32_t max_slices;        // per job
 	uint64_t arena_words;       // u32 words of slice storage per slot
 	int32_t initial_bw, ramp_bw;
+	uint32_t sparse_bw;         // the kernel variant with the sparse method: the bandwidth its per-slot tables are laid out for (else 0)
+	uint32_t reserved;
 };
 
 // row code helpers (host side builds them; GraphAligner.h:2039-2110 for the match sets)

@@ -98,6 +98,7 @@ inline VU gather64(const uint64_t* p, const VI& idx) { VU r; for (int i = 0; i <
 // word `word` of the 16-word record of element idx (64-bit addressing: idx is an unsigned 32-bit element number)
 inline VI gather_rec(const uint32_t* p, const VI& idx, int word) { VI r; for (int i = 0; i < LANES; i++) r.v[i] = (int)p[(uint64_t)(uint32_t)idx.v[i] * 16 + (uint32_t)word]; return r; }
 template <typename T> inline void scatter(T* p, const VI& idx, const VI& x, const VB& m) { for (int i = 0; i < LANES; i++) if (m.v[i]) p[idx.v[i]] = (T)x.v[i]; }
+inline void scatter64(uint64_t* p, const VI& idx, const VU& x, const VB& m) { for (int i = 0; i < LANES; i++) if (m.v[i]) p[idx.v[i]] = x.v[i]; }
 // a value every lane holds identically, handed to the scalar unit
 inline int wave_uniform(int x) { return x; }
 inline void wave_sync() {}
@@ -174,6 +175,7 @@ template <typename T> GA_FN VI gather(const T* p, VI idx) { return (int)p[idx]; 
 GA_FN VU gather64(const uint64_t* p, VI idx) { return p[idx]; }
 GA_FN VI gather_rec(const uint32_t* p, VI idx, int word) { return (int)p[(uint64_t)(uint32_t)idx * 16 + (uint32_t)word]; }
 template <typename T> GA_FN void scatter(T* p, VI idx, VI x, VB m) { if (m) p[idx] = (T)x; }
+GA_FN void scatter64(uint64_t* p, VI idx, VU x, VB m) { if (m) p[idx] = x; }
 // one wave per workgroup: orders this wave's LDS / global traffic (s_waitcnt + s_barrier)
 GA_FN int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 GA_FN void wave_sync() { __syncthreads(); }

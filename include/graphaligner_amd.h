@@ -39,7 +39,9 @@ typedef enum ga_status {
 	GA_S_OK = 0,
 	/* per-read outcomes (ga_read_result.status) */
 	GA_S_ASSERTION = 1,         /* the reference's always-on assert() throws for this read (Aligner.cpp:143) */
-	GA_S_UNSUPPORTED_BAND = 2,  /* band >= 200000 bp: reference uses its sparse method (GraphAligner.h:2483); not built */
+	GA_S_UNSUPPORTED_BAND = 2,  /* internal: a band of >= 200000 bp, where the reference uses its sparse method (GraphAligner.h:2483); resolved by the
+	                               last kernel variant, which carries that method and the backtrace override -- returned only when that pass
+	                               could not get its device memory */
 	GA_S_BAD_SEED = 3,          /* seed node id unknown: std::out_of_range in the reference (GraphAligner.h:423) */
 	GA_S_CAPACITY = 10,         /* device buffers too small even after the automatic retry */
 	GA_S_UNSUPPORTED_CYCLE = 20,/* internal: band subgraph has a cycle (GraphAligner.h:2362-2397); resolved by the general kernel variants, not returned */

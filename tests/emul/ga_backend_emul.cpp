@@ -42,13 +42,16 @@ struct EmulBatch : GaBackendBatch
 	uint64_t poolTop = 0;
 	uint64_t retried = 0;
 
-	template <int MAXN, bool GENERAL> void runOne(uint32_t job, uint32_t capCols, uint64_t arenaWords, uint32_t traceCap)
+	template <int MAXN, bool GENERAL, bool SPARSE = false> void runOne(uint32_t job, uint32_t capCols, uint64_t arenaWords, uint32_t traceCap)
 	{
 		std::vector<uint32_t> endA(capCols), endB(capCols), arena(arenaWords), sliceOff(cfg.max_slices + 1);
 		std::vector<uint8_t> flags(cfg.max_slices + 1);
 		std::vector<uint8_t> staging(traceCap + 64);
 		std::vector<uint32_t> ckpt(cfg.max_slices + 2), below(cfg.max_slices + 1);
-		gak::Slot slot{endA.data(), endB.data(), arena.data(), sliceOff.data(), flags.data(), staging.data(), ckpt.data(), below.data()};
+		const uint32_t maxBw = (uint32_t)std::max(std::max(cfg.initial_bw, cfg.ramp_bw), 1);
+		std::vector<uint8_t> sparse(SPARSE ? gak::sparse_mem_bytes(maxBw) : 0);
+		std::vector<uint32_t> ovr(SPARSE ? 2 * (cfg.max_slices + 2) : 0);
+		gak::Slot slot{endA.data(), endB.data(), arena.data(), sliceOff.data(), flags.data(), staging.data(), ckpt.data(), below.data(), SPARSE ? sparse.data() : nullptr, SPARSE ? ovr.data() : nullptr, maxBw};
 		GaLaunch L;
 		memset(&L, 0, sizeof(L));
 		L.graph = g->dev; L.hmm = &g->hmm; L.rows = rows.data(); L.jobs = jobs.data(); L.outs = outs.data();
@@ -56,7 +59,7 @@ struct EmulBatch : GaBackendBatch
 		L.n_jobs = (uint32_t)jobs.size(); L.trace_cap = traceCap; L.cap_cols = capCols; L.max_slices = cfg.max_slices;
 		L.arena_words = arenaWords; L.initial_bw = cfg.initial_bw; L.ramp_bw = cfg.ramp_bw;
 		auto ws = std::make_unique<gak::WaveState<MAXN>>();
-		gak::run_job<MAXN, GENERAL>(L, *ws, slot, job);
+		gak::run_job<MAXN, GENERAL, SPARSE>(L, *ws, slot, job);
 	}
 
 	// the lanes = reads program (ga_lanes.h): a wave's 64 lanes are run one after the other through each phase; the points
@@ -148,8 +151,14 @@ struct EmulBatch : GaBackendBatch
 		for (uint32_t j = 0; j < jobs.size(); j++)
 		{
 			uint32_t slices = jobs[j].n_rows / 64;
-			auto finalStatus = [](int s) { return s == GA_OK || s == GA_ASSERTION || s == GA_UNSUPPORTED_BAND || s == GA_BAD_SEED; };
+			auto finalStatus = [](int s) { return s == GA_OK || s == GA_ASSERTION || s == GA_BAD_SEED; };
 			if (lanesFirst && finalStatus(outs[j].status)) { lanesDone++; continue; }
+			if (lanesFirst && outs[j].status == GA_UNSUPPORTED_BAND)
+			{
+				retried++;
+				runOne<256, true, true>(j, 2000000, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 256 + 6 * 300000), jobs[j].n_rows * 8 + 4096);
+				continue;
+			}
 			// deliberately small first-try capacities so the retry ladder is exercised too
 			runOne<32, false>(j, 2048, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 40 + 5 * 700), jobs[j].n_rows * 2 + 512);
 			auto capacity = [](int s) { return s == GA_CAP_NODES || s == GA_CAP_COLS || s == GA_CAP_ARENA || s == GA_CAP_TRACE || s == GA_CAP_HEAP; };
@@ -159,6 +168,12 @@ struct EmulBatch : GaBackendBatch
 				runOne<64, true>(j, 4096, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 64 + 5 * 1500) * 2, jobs[j].n_rows * 3 + 1024);
 			if (capacity(outs[j].status) || general(outs[j].status))
 				runOne<256, true>(j, 200000, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 256 + 5 * 20000) * 3, jobs[j].n_rows * 8 + 4096);
+			// a band of 200 000 cells or more: the variant that carries the sparse method and the backtrace override (ga_sparse.h)
+			if (outs[j].status == GA_UNSUPPORTED_BAND)
+			{
+				retried++;
+				runOne<256, true, true>(j, 2000000, 64 + (uint64_t)slices * (gak::kSliceHdrWords + 3 * 256 + 6 * 300000), jobs[j].n_rows * 8 + 4096);
+			}
 		}
 		if (getenv("GA_EMUL_DEBUG")) { int hist[100] = {0}; for (auto& o : outs) hist[o.status < 100 ? o.status : 99]++; fprintf(stderr, "emul: %zu jobs, %llu finished by the lanes program, %llu retried; final statuses:", jobs.size(), (unsigned long long)lanesDone, (unsigned long long)retried); for (int i = 0; i < 100; i++) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]); fprintf(stderr, "\n"); }
 		return 0;

@@ -331,3 +331,59 @@ def case_full_size_properties(lib_path=None):
     og = ob.OracleGraph(g.nodes, g.edges)
     for i in range(0, 128, 16):
         pc.compare_read(r1[i], og.align(reads[i], [seeds[i]], 35), "full-size %d" % i)
+
+
+SPARSE_FANS = [(8, 30000, 150, 600, 35, 0), (8, 30000, 400, 1000, 10, 0), (5, 50000, 100, 333, 35, 60), (12, 20000, 200, 500, 20, 45), (40, 6000, 250, 400, 35, 0)]
+
+
+def case_sparse_method_and_override(branches, branch_len, shared, stem, bw, ramp, lib_path=None):
+    """bands of 200 000 cells and more: the reference leaves its bit vectors for calculateSliceAlternate (GraphAligner.h:2148-2329)
+    and keeps the window's slices to work the traceback out at once (BacktraceOverride, :167-354).  Fan graphs (synth.FanGraph): a
+    stem that ends in many long branches with a common beginning, so that the projected band holds all of them.  Reads through the
+    fan forwards (sparse slices between bit-vector ones, in both orders), with a seed past the fan (the backward part meets it from the
+    other strand: a many-to-one join), and the sharp edges the reference has here."""
+    import oracle_binding as ob
+    g = synth.FanGraph(head_len=200, stem_len=stem, n_branches=branches, branch_len=branch_len, shared=shared, seed=branches)
+    rng = np.random.default_rng(branches * 11 + bw)
+    reads, seeds = [], []
+    for k in range(4):
+        r, s = g.read_through(int(rng.integers(0, branches)), 0, 1400 + 450 * k, rng)
+        reads.append(r); seeds.append(s)
+    # seeds inside a branch, 600-1100 bases into it: the backward part runs back over the branch's start, the stem and the head
+    for k in range(3):
+        b = int(rng.integers(0, branches))
+        depth = 600 + 250 * k
+        path = np.concatenate([g.head, g.stem, g.branches[b][:depth + 900]])
+        pre = synth.add_errors(path[:len(g.head) + len(g.stem) + depth], 0.03, 0.03, 0.03, rng).tobytes().decode()
+        post = synth.add_errors(path[len(g.head) + len(g.stem) + depth:], 0.03, 0.03, 0.03, rng).tobytes().decode()
+        reads.append(pre + post); seeds.append((3 + b, len(pre), False))
+    devs, oras = pc.check_parity(g.nodes, g.edges, reads, seeds, bw, ramp=ramp, lib_path=lib_path, ctx="fan %d x %d bw%d/%d" % (branches, branch_len, bw, ramp))
+    n_sparse = sum(o["sparse_slices"] for o in oras)
+    n_windows = sum(o["override_traces"] for o in oras)
+    n_ok = sum(1 for d in devs if d["status"] == 0 and not d["failed"])
+    assert n_sparse >= 8 and n_windows >= 1 and n_ok >= 3, (n_sparse, n_windows, n_ok)
+    return devs, oras
+
+
+def case_sparse_sharp_edges(lib_path=None):
+    """what the reference does around the sparse method that is not an alignment: undefined behaviour at bandwidth 0, the assertion
+    when an override window starts at slice 0, and the 16-bit frozen scores that a long node's untouched columns do not fit"""
+    g = synth.FanGraph(head_len=200, stem_len=800, n_branches=8, branch_len=30000, shared=300, seed=3)
+    rng = np.random.default_rng(1)
+    read = synth.add_errors(np.concatenate([g.stem, g.branches[2]])[:1500], 0.03, 0.03, 0.03, rng).tobytes().decode()
+    # a seed on the stem: slice 0 projects every branch and goes sparse at the ramp width (slice-0 quirk, :2612)
+    devs, oras = pc.check_parity(g.nodes, g.edges, [read, read], [(2, 0, False), (2, 0, False)], 35, ramp=0, lib_path=lib_path, ctx="sparse at bandwidth 0")
+    assert oras[0]["status"] == 1 and devs[0]["status"] == 1
+    devs, oras = pc.check_parity(g.nodes, g.edges, [read], [(2, 0, False)], 35, ramp=70, lib_path=lib_path, ctx="override window at slice 0")
+    assert oras[0]["status"] == 1 and "overrideLastJ" in oras[0]["message"]
+    # one node of 209 100 bp behind two short ones (the literal single-contig case, unsplit): the sparse slice that reaches it leaves
+    # its untouched columns at minimum + length + bandwidth + 1 (:2546-2549) -- assert(... < 65535) in the frozen slice (NodeSlice.h:372)
+    contig = synth.random_genome(210000, 77)
+    nodes = [(1, contig[:300].tobytes().decode()), (2, contig[300:900].tobytes().decode()), (3, contig[900:].tobytes().decode())]
+    edges = [(1, False, 2, False), (2, False, 3, False)]
+    reads = [synth.add_errors(contig[a:a + 1500], 0.03, 0.03, 0.03, rng).tobytes().decode() for a in (0, 100)]
+    devs, oras = pc.check_parity(nodes, edges, reads, [(1, 0, False), (1, 100, False)], 35, ramp=0, lib_path=lib_path, ctx="a 209 kbp node")
+    assert all(o["status"] == 1 and "65535" in o["message"] for o in oras)
+    # ... and a seed ON that node without a ramp width: bandwidth 0 again
+    devs, oras = pc.check_parity(nodes, edges, [synth.add_errors(contig[5000:6500], 0.03, 0.03, 0.03, rng).tobytes().decode()], [(3, 0, False)], 35, ramp=0, lib_path=lib_path, ctx="seed on a 209 kbp node")
+    assert oras[0]["status"] == 1 and devs[0]["status"] == 1

@@ -66,3 +66,12 @@ def test_unknown_seed_node_reports_bad_seed(lib):
 
 def test_gfa_loader_matches_node_edge_api(lib):
     cases.case_gfa_loader_matches_node_edge_api(lib)
+
+
+@pytest.mark.parametrize("branches,branch_len,shared,stem,bw,ramp", cases.SPARSE_FANS)
+def test_sparse_method_and_override(lib, branches, branch_len, shared, stem, bw, ramp):
+    cases.case_sparse_method_and_override(branches, branch_len, shared, stem, bw, ramp, lib)
+
+
+def test_sparse_sharp_edges(lib):
+    cases.case_sparse_sharp_edges(lib)

@@ -80,6 +80,18 @@ def test_gfa_loader_matches_node_edge_api():
     cases.case_gfa_loader_matches_node_edge_api()
 
 
+@pytest.mark.parametrize("branches,branch_len,shared,stem,bw,ramp", cases.SPARSE_FANS)
+def test_sparse_method_and_override(branches, branch_len, shared, stem, bw, ramp):
+    """bands of >= 200 000 cells: calculateSliceAlternate and the backtrace override on the device (ga_sparse.h)"""
+    devs, oras = cases.case_sparse_method_and_override(branches, branch_len, shared, stem, bw, ramp)
+    # (such jobs are finished by the last kernel of the ladder, never by the first pass)
+    assert all(d["kernel_pass"] > 0 for d, o in zip(devs, oras) if o["sparse_slices"] > 0)
+
+
+def test_sparse_sharp_edges():
+    cases.case_sparse_sharp_edges()
+
+
 def test_full_size_properties():
     cases.case_full_size_properties()
 
