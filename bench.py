@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--accuracy", type=int, default=256, help="reads scored against the simulator's true paths with the reference's criterion (CompareAlignments.cpp)")
     ap.add_argument("--pipeline-chunks", type=int, default=4, help="chunks of the batch's size run through the overlapped host pipeline for detail.pipelined_host_to_host_Gbp_s (0 = skip)")
     ap.add_argument("--check", type=int, default=64, help="reads compared with the oracle after the run (includes failed / later-pass reads)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: ONE read set of --reads reads for the whole job, chunks pulled by the ranks from the shared queue "
+                                                          "(sharding.align_queued); default is weak scaling, --reads per GPU")
+    ap.add_argument("--kernel-only", action="store_true", help="time the device passes alone (profiling runs); the default step also brings the results to host memory")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,6 +86,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend)
+        # the host stages (job building, result assembly) are threaded: the ranks of one node share its cores
+        os.environ.setdefault("GA_HOST_THREADS", str(max(1, _usable_cores() // world)))
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     red_dev = "cuda" if backend == "nccl" else "cpu"
@@ -108,7 +113,8 @@ def main():
         g = synth.SynthGraph(synth.random_genome(args.genome, 47), node_len=args.node_len, snp_every=45, indel_every=500, seed=48)
     e_sub, e_ins, e_del = (float(x) for x in args.errors.split(","))
     truth = []
-    reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=e_sub, ins=e_ins, dele=e_del, seed=43 + 1000 * rank, truth=truth)
+    # (strong scaling: every rank holds the same read set, as every thread of the reference's driver does, Aligner.cpp:107-117)
+    reads, seeds = synth.simulate_reads(g, args.reads, args.read_len, sub=e_sub, ins=e_ins, dele=e_del, seed=43 + (0 if args.strong else 1000 * rank), truth=truth)
     t_gen = time.time() - t0
     t0 = time.time()
     lib_path = entry.build_stamped() if args.stamps else args.lib
@@ -134,13 +140,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # One step = one pass of the hot path over one batch whose reads, match words and job list are resident in HBM: every kernel pass
+    # (band projection, fill, HMM stop test, traceback) AND the way back -- download of the traceback's node runs / moves and assembly
+    # of the AlignmentResults in host memory (traceToAlignment / mergeAlignments).  --kernel-only leaves the way
+    # back out (the figure round 2 printed as `value`; it stays in detail.kernel_only_Gbp_s and in the roofline).
+    from graphaligner_amd import sharding
+    strong_chunk = max(64, min(65536, (args.reads + 4 * world - 1) // (4 * world)))
+    def one_step():
+        if args.strong and world > 1:
+            return sharding.align_queued(graph, reads, seeds, args.bandwidth, dist=dist, chunk_reads=strong_chunk, summary=True)
         batch.run()
+        return None if args.kernel_only else batch.collect(summary=True)
+    for _ in range(args.warmup):
+        one_step()
     barrier()
     kernel_ms, main_kernel_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.run()
+        one_step()
         sk = batch.stats()
         kernel_ms.append(sk["kernel_ms"])
         main_kernel_ms.append(sk["main_kernel_ms"])
@@ -151,6 +168,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.strong and world > 1:
+        batch.run()       # (untimed: the statistics and the roofline below describe one GPU's pass over the whole read set)
     # what was aligned (reads returned with failed = 0), from one collect after the timed region
     t0 = time.time()
     summary = batch.collect(summary=True)
@@ -185,12 +204,12 @@ def main():
     lens = np.array([len(r) for r in reads], dtype=np.int64)
     aligned_bp = int(lens[summary["failed"] == 0].sum())
     n_failed = int((summary["failed"] != 0).sum())
-    if world > 1:
+    if world > 1 and not args.strong:
         t = torch.tensor([float(aligned_bp)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         aligned_total = float(t.item())
     else:
-        aligned_total = float(aligned_bp)
+        aligned_total = float(aligned_bp)          # (strong scaling: the one read set, whichever rank aligned which chunk)
 
     if rank != 0:
         if world > 1:
@@ -203,7 +222,9 @@ def main():
     main_ms = float(np.mean(main_kernel_ms))           # the dominant kernel alone: the first pass over all jobs
     variant = int(st["main_variant"])
     kernel_name = ("ga_lanes_kernel<%d,%d>" % (variant // 1000, 32 if variant % 10 else 64)) if variant > 0 else "ga_extend_kernel<%d,false>" % (-variant if variant else 64)
-    dom_ms = main_ms if variant else k_ms
+    # the roofline prices the dominant kernel: the first pass when it finished every job; when jobs went on to the ladder their column
+    # updates were (re)computed by later passes, and the time of ALL passes is what the batch's column updates are divided by
+    dom_ms = main_ms if (variant and st["jobs_retried"] == 0) else k_ms
     achieved = BYTES_PER_COLUMN_UPDATE * st["column_updates"] / (dom_ms * 1e-3) / 1e9
     # HBM traffic per launch: PMC counters cannot be read from inside this process, so the per-column-update figure measured with
     # rocprofv3 --pmc on this kernel and this workload (tools/pmc_lanes.sh -> profiles/r2_hbm_traffic.json) is scaled to this launch
@@ -227,10 +248,11 @@ def main():
     out = {
         "metric": "aligned Gbp/sec (whole node), 10kb ONT reads vs chr-scale GFA",
         "value": round(value, 4), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": workload, "reads_per_gpu": args.reads, "read_len": args.read_len, "bandwidth": args.bandwidth, "graph_bp_both_strands": int(graph.bp),
-                   "parallelism": "reads sharded, graph replicated, no collective"},
+        "config": {"workload": workload, ("reads_total" if args.strong else "reads_per_gpu"): args.reads, "read_len": args.read_len, "bandwidth": args.bandwidth, "graph_bp_both_strands": int(graph.bp),
+                   "step": ("device passes only" if args.kernel_only else "reads / match words / jobs resident in HBM -> every kernel pass -> AlignmentResults assembled in host memory"),
+                   "parallelism": ("one read set, chunks of %d reads pulled from a shared queue, graph replicated, no collective" % strong_chunk) if args.strong else "reads sharded, graph replicated, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": traffic, "traffic_source": traffic_note, "kernel": kernel_name, "kernel_ms": round(dom_ms, 3), "frac_of_measured_stream_copy": round(achieved / HBM_STREAM_GBS, 5),
                      "column_updates_per_launch": int(st["column_updates"]), "bytes_per_column_update": BYTES_PER_COLUMN_UPDATE},
@@ -287,8 +309,8 @@ def main():
             names = ["band:map_order", "band:previous_band", "band:heap", "band:slots", "band:processing_order", "traceback", "band phase", "fill"]
         if os.environ.get("GA_STAMPS_LEVEL") in ("3", "4"):
             tot = float(st["stamps"][5] + st["stamps"][6] + st["stamps"][7]) or 1.0
-
-        tot = float(st["stamps"][0] + st["stamps"][1] + st["stamps"][4] + st["stamps"][5]) or 1.0
+        else:
+            tot = float(st["stamps"][0] + st["stamps"][1] + st["stamps"][4] + st["stamps"][5]) or 1.0
         out["detail"]["phase_share"] = {n: round(v / tot, 4) for n, v in zip(names, st["stamps"])}
         out["detail"]["cycles_per_job"] = round(tot / max(1, st["n_jobs"]))
         out["detail"]["stamps_raw"] = [int(v) for v in st["stamps"]]

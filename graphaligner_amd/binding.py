@@ -63,7 +63,7 @@ class GaNamedSeed(C.Structure):
 EXPORTS = ["ga_graph_create", "ga_graph_destroy", "ga_graph_add_node", "ga_graph_add_edge", "ga_graph_add_bigraph_node",
            "ga_graph_add_bigraph_edge", "ga_graph_finalize", "ga_graph_load_gfa", "ga_graph_upload", "ga_graph_node_count", "ga_graph_bp",
            "ga_align_batch", "ga_results_free", "ga_batch_prepare", "ga_batch_run", "ga_batch_collect", "ga_batch_free", "ga_batch_stats",
-           "ga_graph_load_gfa_split", "ga_graph_split_lookup", "ga_results_unsplit", "ga_graph_load_vg", "ga_gam_decode_seeds", "ga_results_encode_gam", "ga_bytes_free", "ga_status_string", "ga_version"]
+           "ga_graph_set_neighbors", "ga_graph_load_gfa_split", "ga_graph_split_lookup", "ga_results_unsplit", "ga_graph_load_vg", "ga_gam_decode_seeds", "ga_results_encode_gam", "ga_bytes_free", "ga_status_string", "ga_version"]
 
 _libs = {}
 
@@ -80,6 +80,7 @@ def load(path=None):
     L.ga_graph_destroy.argtypes = [C.c_void_p]
     L.ga_graph_add_node.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_size_t, C.c_int]
     L.ga_graph_add_edge.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    L.ga_graph_set_neighbors.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ga_graph_add_bigraph_node.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_size_t]
     L.ga_graph_add_bigraph_edge.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int]
     L.ga_graph_finalize.argtypes = [C.c_void_p, C.c_int]

@@ -163,8 +163,11 @@ struct DevGraph : GaBackendGraph
 	size_t poolBytes = 0;
 	bool poolBusy = false;
 	~DevGraph() override { hipSetDevice(device); for (void* p : allocs) hipFree(p); if (pool) hipFree(pool); if (hostPool) hipHostFree(hostPool); }
+	// (one graph can serve batches run from several host threads: the pool changes hands under a lock)
+	std::mutex poolLock;
 	uint8_t* takePool(size_t bytes)
 	{
+		std::lock_guard<std::mutex> lock(poolLock);
 		if (poolBusy) return nullptr;
 		if (bytes > poolBytes)
 		{
@@ -176,7 +179,8 @@ struct DevGraph : GaBackendGraph
 		poolBusy = true;
 		return pool;
 	}
-	void givePool() { poolBusy = false; }
+	void givePool() { std::lock_guard<std::mutex> lock(poolLock); poolBusy = false; }
+	size_t poolBytesIfFree() { std::lock_guard<std::mutex> lock(poolLock); return poolBusy ? 0 : poolBytes; }
 	// pinned host buffer for the moves on their way back (page-locking half a GB per batch would cost more than the copy)
 	std::mutex hostLock;
 	uint8_t* hostPool = nullptr;
@@ -209,9 +213,25 @@ struct DevGraph : GaBackendGraph
 	}
 };
 
+// the few switches the library reads from the environment, once per batch: GA_LANES (1 / 0: force which kernel goes first -- the GPU
+// parity tests run every case both ways), GA_DEBUG_PASSES (one line per launch on stderr) and a test hook for the trace pool's size
+struct Knobs
+{
+	int lanes = -1;                 // -1: by graph shape
+	bool debugPasses = false;
+	uint64_t tracePoolBytes = 0;    // 0: sized from the batch
+	Knobs()
+	{
+		if (const char* e = getenv("GA_LANES")) lanes = atoi(e) != 0 ? 1 : 0;
+		debugPasses = getenv("GA_DEBUG_PASSES") != nullptr;
+		if (const char* t = getenv("GA_TEST_TRACE_POOL_BYTES")) tracePoolBytes = (uint64_t)atoll(t) & ~3ull;
+	}
+};
+
 struct DevBatch : GaBackendBatch
 {
 	DevGraph* g = nullptr;
+	Knobs knobs;
 	hipStream_t stream = nullptr;
 	hipEvent_t evA = nullptr, evB = nullptr;
 	std::vector<void*> allocs;
@@ -297,6 +317,8 @@ struct DevBatch : GaBackendBatch
 		// one byte per move (a path makes at most ~1.5 moves per row), or 20 bytes per node run: room for a node change every 5 rows
 		// (a job that does not fit reports GA_CAP_TRACE and is rerun by the ladder, which writes moves)
 		L.trace_pool_cap = ((totalRows * (cfg.emit_runs ? 4 : 1) + totalRows / 2 + 256ull * jobs.size() + 4096) + 3) & ~3ull;
+		// (test hook: a deliberately small pool, so that the claims' overflow path runs -- tests/parity_cases.py)
+		if (knobs.tracePoolBytes) L.trace_pool_cap = knobs.tracePoolBytes;
 		if (alloc(&L.traces, L.trace_pool_cap)) return GA_E_DEVICE;
 		HIP_OK(hipStreamSynchronize(stream));
 		return 0;
@@ -321,7 +343,8 @@ struct DevBatch : GaBackendBatch
 	{
 		size_t freeB = 0, totalB = 0;
 		if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 0;
-		return (size_t)((freeB + (g->poolBusy ? privateBytes : g->poolBytes)) * 0.85);
+		const size_t poolFree = g->poolBytesIfFree();
+		return (size_t)((freeB + (poolFree ? poolFree : privateBytes)) * 0.85);
 	}
 	int uploadList(const std::vector<uint32_t>& list)
 	{
@@ -374,9 +397,9 @@ struct DevBatch : GaBackendBatch
 		const uint64_t fit = scratchBudget() / std::max<uint64_t>(lay.bytes, 1);
 		const uint64_t slotsHere = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g->cus * wavesPerCu, fit));
 		// a batch that does not fill every wave slot with LW jobs is spread over all of them: a wave's steps cost the same with
-		// fewer lanes, and fewer lanes wait for each other less (GA_LANES_SPREAD=0: full waves)
+		// fewer lanes, and fewer lanes wait for each other less
 		uint32_t lanesPer = LW;
-		if (!(getenv("GA_LANES_SPREAD") && atoi(getenv("GA_LANES_SPREAD")) == 0) && list.size() < slotsHere * LW)
+		if (list.size() < slotsHere * LW)
 			lanesPer = (uint32_t)std::min<uint64_t>(LW, std::max<uint64_t>(8, (list.size() + slotsHere - 1) / slotsHere));
 		P.lanes_per_wave = lanesPer;
 		const uint64_t groups = (list.size() + lanesPer - 1) / lanesPer;
@@ -394,7 +417,7 @@ struct DevBatch : GaBackendBatch
 			float ms = 0;
 			rc = afterPass(ms);
 			if (first) { st.main_ms = ms; st.main_variant = N * 1000 + 80 + (LW == 64 ? 0 : 1); st.slots = waves; st.waves_per_cu = wavesPerCu; st.scratch_bytes = (uint64_t)waves * lay.bytes; }
-			if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: lanes pass <%d,%d>: %zu jobs on %u waves (%.1f GB scratch), %.2f ms\n", N, LW, list.size(), waves, waves * (double)lay.bytes / 1e9, ms);
+			if (knobs.debugPasses) fprintf(stderr, "graphaligner_amd: lanes pass <%d,%d>: %zu jobs on %u waves (%.1f GB scratch), %.2f ms\n", N, LW, list.size(), waves, waves * (double)lay.bytes / 1e9, ms);
 #if GA_STAMPS == 3
 			{
 				uint64_t lo = ~0ull, hi = 0, n = 0; double life = 0, cyc = 0, lateStart = 0;
@@ -460,7 +483,7 @@ struct DevBatch : GaBackendBatch
 			hipLaunchKernelGGL((ga_extend_kernel<MAXN, GENERAL, SPARSE>), dim3(rslots), dim3(64), 0, stream, Rl);
 			float ms = 0;
 			rc = afterPass(ms);
-			if (getenv("GA_DEBUG_PASSES")) fprintf(stderr, "graphaligner_amd: wave-per-read pass <%d,%d>: %zu jobs on %u slots, %.2f ms\n", MAXN, (int)GENERAL, again.size(), rslots, ms);
+			if (knobs.debugPasses) fprintf(stderr, "graphaligner_amd: wave-per-read pass <%d,%d>: %zu jobs on %u slots, %.2f ms\n", MAXN, (int)GENERAL, again.size(), rslots, ms);
 		}
 		if (fromPool) g->givePool();
 		return rc;
@@ -483,13 +506,11 @@ struct DevBatch : GaBackendBatch
 		// equally long nodes (mean node length >= 40 bp: linear and sparsely branching graphs) every lane is busy; on graphs chopped
 		// into short uneven nodes the wave-per-read kernel is still the faster one and goes first.  GA_LANES=1 / 0 forces the choice.
 		const double meanNode = g->g.n_nodes > 2 ? (double)g->totalBp / (double)(g->g.n_nodes - 2) : 64.0;
-		const bool useLanes = getenv("GA_LANES") ? atoi(getenv("GA_LANES")) != 0 : meanNode >= 40;
-		const int half = getenv("GA_LANES_PER_WAVE") && atoi(getenv("GA_LANES_PER_WAVE")) == 32;
+		const bool useLanes = knobs.lanes >= 0 ? knobs.lanes != 0 : meanNode >= 40;
 		int rc = 0;
 		if (useLanes)
 		{
-			int startN = meanNode >= 40 ? 0 : meanNode >= 14 ? 1 : 2;
-			if (getenv("GA_LANES_N")) startN = atoi(getenv("GA_LANES_N"));
+			const int startN = meanNode >= 40 ? 0 : meanNode >= 14 ? 1 : 2;
 			std::vector<uint32_t> list = orderHost;
 			bool first = true;
 			for (int n = startN; n <= 2 && !list.empty() && !rc; n++)
@@ -497,7 +518,7 @@ struct DevBatch : GaBackendBatch
 				// later sizes are only worth a launch of their own for enough jobs to fill waves; stragglers take the wave-per-read ladder
 				if (!first && list.size() < 512) break;
 				// (10 / 24 / 56 band nodes per lane = 4 / 2 / 1 waves per CU next to the 12.8 KB block image)
-				if (n == 0) rc = half ? lanesPass<10, 32>(list, getenv("GA_ROWS_PER_SLICE") ? atoi(getenv("GA_ROWS_PER_SLICE")) : 400, first) : lanesPass<10, 64>(list, 400, first);
+				if (n == 0) rc = lanesPass<10, 64>(list, 400, first);
 				else if (n == 1) rc = lanesPass<24, 64>(list, 1024, first);
 				else rc = lanesPass<56, 64>(list, 2560, first);
 				first = false;
@@ -527,7 +548,8 @@ struct DevBatch : GaBackendBatch
 		if (rc) return rc;
 		// bands of 200 000 cells and more (the reference's sparse method and backtrace override, ga_sparse.h): a fallback, run for the
 		// jobs that met such a band, with room for every column of every node such a slice touches
-		rc = retryPass<256, true, true>(1u << 20, 3 * 256 + 5 * 20000, 8, 1, false, false, 48ull << 20);
+		// (also the last resort for what the passes before could not hold: bit-vector bands may have up to 199 999 columns)
+		rc = retryPass<256, true, true>(1u << 20, 3 * 256 + 5 * 20000, 8, 1, true, true, 48ull << 20);
 		for (int k = 0; k < 8; k++) { st.stamps[k] = 0; for (auto& o : outs) st.stamps[k] += o.stamps[k]; }
 		return rc;
 	}

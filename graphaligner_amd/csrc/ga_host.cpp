@@ -94,6 +94,8 @@ struct ga_graph
 	std::unordered_map<int64_t, uint32_t> lookup;
 	std::vector<int64_t> ids;
 	std::vector<std::pair<uint32_t, uint32_t>> edgeList;      // (from, to) node indices in the order the edges were added; the CSR lists are built at Finalize
+	// nodes whose finished neighbour lists were handed over verbatim (ga_graph_set_neighbors): node index -> (in-list, out-list)
+	std::unordered_map<uint32_t, std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> givenLists;
 	std::vector<uint8_t> reverse;
 	std::vector<uint8_t> bases;         // 0..3, 4 for the dummy columns
 	GaFlatGraph flat;
@@ -154,6 +156,19 @@ static int addEdge(ga_graph* g, int64_t from, int64_t to)
 	return GA_S_OK;
 }
 
+// a node's inNeighbors / outNeighbors exactly as a finished AlignmentGraph holds them (AlignmentGraph.h:49-50)
+static int setNeighbors(ga_graph* g, int64_t id, const int64_t* in, size_t nIn, const int64_t* out, size_t nOut)
+{
+	if (g->finalized) return GA_E_INVALID;
+	auto me = g->lookup.find(id);
+	if (me == g->lookup.end()) return GA_E_INVALID;
+	std::pair<std::vector<uint32_t>, std::vector<uint32_t>> lists;
+	for (size_t k = 0; k < nIn; k++) { auto it = g->lookup.find(in[k]); if (it == g->lookup.end()) return GA_E_INVALID; lists.first.push_back(it->second); }
+	for (size_t k = 0; k < nOut; k++) { auto it = g->lookup.find(out[k]); if (it == g->lookup.end()) return GA_E_INVALID; lists.second.push_back(it->second); }
+	g->givenLists[me->second] = std::move(lists);
+	return GA_S_OK;
+}
+
 static std::string revcompACGT(const char* seq, size_t len)
 {
 	std::string r(len, 'N');
@@ -186,13 +201,25 @@ static int finalizeGraph(ga_graph* g, int overlap)
 			std::vector<uint32_t> inAt(inCount.begin(), inCount.end() - 1), outAt(outCount.begin(), outCount.end() - 1);
 			for (const auto& e : E) { outAll[outAt[e.first]++] = e.second; inAll[inAt[e.second]++] = e.first; }
 		}
-		auto compact = [&](const std::vector<uint32_t>& count, const std::vector<uint32_t>& all, std::vector<uint32_t>& off, std::vector<uint32_t>& nbr) {
+		auto compact = [&](const std::vector<uint32_t>& count, const std::vector<uint32_t>& all, std::vector<uint32_t>& off, std::vector<uint32_t>& nbr, bool inLists) {
 			off.assign(n + 1, 0);
 			nbr.clear();
 			nbr.reserve(all.size() + 1);
 			for (uint32_t i = 0; i < n; i++)
 			{
 				const size_t first = nbr.size();
+				if (!g->givenLists.empty())
+				{
+					auto given = g->givenLists.find(i);
+					if (given != g->givenLists.end())
+					{
+						// a finished list, taken as it is
+						const std::vector<uint32_t>& lst = inLists ? given->second.first : given->second.second;
+						nbr.insert(nbr.end(), lst.begin(), lst.end());
+						off[i + 1] = (uint32_t)nbr.size();
+						continue;
+					}
+				}
 				for (uint32_t k = count[i]; k < count[i + 1]; k++)
 				{
 					bool seen = false;
@@ -203,9 +230,10 @@ static int finalizeGraph(ga_graph* g, int overlap)
 			}
 			nbr.push_back(0);
 		};
-		compact(inCount, inAll, f.in_off, f.in_nbr);
-		compact(outCount, outAll, f.out_off, f.out_nbr);
+		compact(inCount, inAll, f.in_off, f.in_nbr, true);
+		compact(outCount, outAll, f.out_off, f.out_nbr, false);
 		std::vector<std::pair<uint32_t, uint32_t>>().swap(g->edgeList);
+		g->givenLists.clear();
 	}
 	g->hmm = buildHmm();
 	return GA_S_OK;
@@ -543,6 +571,10 @@ ga_graph_t* ga_graph_create(void) { return new ga_graph(); }
 void ga_graph_destroy(ga_graph_t* g) { if (g) { delete g->device; delete g; } }
 int ga_graph_add_node(ga_graph_t* g, int64_t id, const char* seq, size_t len, int rev) { return g ? addNode(g, id, seq, len, rev != 0) : GA_E_INVALID; }
 int ga_graph_add_edge(ga_graph_t* g, int64_t from, int64_t to) { return g ? addEdge(g, from, to) : GA_E_INVALID; }
+int ga_graph_set_neighbors(ga_graph_t* g, int64_t id, const int64_t* in, size_t nIn, const int64_t* out, size_t nOut)
+{
+	return g && (in || nIn == 0) && (out || nOut == 0) ? setNeighbors(g, id, in, nIn, out, nOut) : GA_E_INVALID;
+}
 int ga_graph_add_bigraph_node(ga_graph_t* g, int64_t id, const char* seq, size_t len)
 {
 	if (!g) return GA_E_INVALID;
@@ -944,6 +976,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		if (sp.early != GA_S_OK || sp.bwJob >= 0 || sp.fwJob < 0 || sp.pos != 0) return false;
 		const GaJobOut& o = outs[sp.fwJob];
 		if (o.status != GA_OK) return false;
+		rr.reserved = (int32_t)o.reserved2;                                      // which kernel pass finished the job (0 = the first)
 		const ReadSeq& seq = b->seqs[ri];
 		for (char c : seq) if (tables().rowCode[(uint8_t)c] & GA_ROW_INVALID) return false;     // (the reference's eager TraceItem pass asserts on these)
 		if (o.n_valid == 0) { rr.column_updates += o.n_columns; rr.status = GA_S_OK; return true; }     // nothing kept: both parts fail (rr stays failed)
@@ -1080,6 +1113,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 			{
 				if (job < 0) continue;
 				rr.column_updates += outs[job].n_columns;
+				rr.reserved = std::max<int32_t>(rr.reserved, (int32_t)outs[job].reserved2);
 				if (outs[job].status != GA_OK) status = mapDeviceStatus(outs[job].status);
 			}
 			if (status != GA_S_OK) break;

@@ -2161,8 +2161,8 @@ GA_FN void run_job(const GaLaunch& L, WaveState<MAXN>& ws, const Slot& slotIn, u
 		{
 			wave_sync();
 			const uint32_t words = (len + 3) / 4;
-			uint64_t at = wave_atomic_add(L.trace_top, (uint64_t)words * 4);
-			if (at + (uint64_t)words * 4 > L.trace_pool_cap) status = GA_CAP_TRACE;
+			const uint64_t at = wave_claim(L.trace_top, (uint64_t)words * 4, L.trace_pool_cap);      // (commits only when it fits)
+			if (at == ~0ull) status = GA_CAP_TRACE;
 			else
 			{
 				uint32_t* dst = (uint32_t*)(L.traces + at);

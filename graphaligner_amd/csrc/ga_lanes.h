@@ -1607,21 +1607,24 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		if (status == GA_OK)
 		{
 			const uint32_t words = emitRuns ? 5 * nRuns : (len + 3) / 4;
+			// the claim only ever commits when it fits (compare-and-swap): an overshoot that is rolled back later could leave the pool's
+			// top below a region another lane claimed in between
+			uint64_t at = 0;
+			bool claimed = false;
 #ifdef GA_EMULATE
-			const uint64_t at = *L.trace_top; *L.trace_top += (uint64_t)words * 4;
+			if (*L.trace_top + (uint64_t)words * 4 <= L.trace_pool_cap) { at = *L.trace_top; *L.trace_top += (uint64_t)words * 4; claimed = true; }
 #else
-			const uint64_t at = atomicAdd((unsigned long long*)L.trace_top, (unsigned long long)words * 4);
-#endif
-			if (at + (uint64_t)words * 4 > L.trace_pool_cap)
 			{
-				status = GA_CAP_TRACE;
-				// (give the claim back: the jobs after this one and the ladder's passes still find room)
-#ifdef GA_EMULATE
-				*L.trace_top -= (uint64_t)words * 4;
-#else
-				atomicAdd((unsigned long long*)L.trace_top, (unsigned long long)(0ull - (uint64_t)words * 4));
-#endif
+				unsigned long long seen = *(volatile unsigned long long*)L.trace_top;
+				while (seen + (unsigned long long)words * 4 <= L.trace_pool_cap)
+				{
+					const unsigned long long prev = atomicCAS((unsigned long long*)L.trace_top, seen, seen + (unsigned long long)words * 4);
+					if (prev == seen) { at = seen; claimed = true; break; }
+					seen = prev;
+				}
 			}
+#endif
+			if (!claimed) status = GA_CAP_TRACE;
 			else
 			{
 				uint32_t* dst = (uint32_t*)(L.traces + at);

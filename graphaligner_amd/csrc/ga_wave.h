@@ -107,6 +107,8 @@ inline uint64_t stamp() { return 0; }
 // one reservation for the whole wave; every lane sees the old value
 inline uint64_t wave_atomic_add(uint64_t* p, uint64_t v) { uint64_t r = *p; *p += v; return r; }
 inline uint32_t wave_atomic_add(uint32_t* p, uint32_t v) { uint32_t r = *p; *p += v; return r; }
+// claim `bytes` of a pool whose top is *p, only if they fit below `cap`; ~0 when they do not (the top is left alone)
+inline uint64_t wave_claim(uint64_t* p, uint64_t bytes, uint64_t cap) { if (*p + bytes > cap) return ~0ull; uint64_t r = *p; *p += bytes; return r; }
 
 #else
 // =========================================================================================
@@ -197,6 +199,24 @@ GA_FN uint64_t wave_atomic_add(uint64_t* p, uint64_t v)
 {
 	unsigned long long r = 0;
 	if (threadIdx.x == 0) r = atomicAdd((unsigned long long*)p, (unsigned long long)v);
+	uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
+	uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32));
+	return ((uint64_t)hi << 32) | lo;
+}
+
+GA_FN uint64_t wave_claim(uint64_t* p, uint64_t bytes, uint64_t cap)
+{
+	unsigned long long r = ~0ull;
+	if (threadIdx.x == 0)
+	{
+		unsigned long long seen = *(volatile unsigned long long*)p;
+		while (seen + bytes <= cap)
+		{
+			const unsigned long long prev = atomicCAS((unsigned long long*)p, seen, seen + (unsigned long long)bytes);
+			if (prev == seen) { r = seen; break; }
+			seen = prev;
+		}
+	}
 	uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r);
 	uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(r >> 32));
 	return ((uint64_t)hi << 32) | lo;

@@ -41,12 +41,19 @@ def make_chunks(lengths, chunk_reads):
     return [[int(i) for i in order[k:k + chunk_reads]] for k in range(0, len(order), chunk_reads)]
 
 
+_queue_calls = 0       # how many queues this process has drawn from: every rank calls align_queued the same number of times, so the
+                       # number names the same queue on all of them
+
+
 class _Counter:
     """the shared "next chunk" counter: the process group's store (a TCP store on 127.0.0.1 for a single node) when there are
-    several ranks, a local integer otherwise"""
+    several ranks, a local integer otherwise.  Every queue gets a key of its own (tag + the call's sequence number): a store key is
+    never reset, so a second queue under the first one's key would find it drained."""
 
-    def __init__(self, dist, key):
-        self.key, self.local, self.store = key, 0, None
+    def __init__(self, dist, tag):
+        global _queue_calls
+        _queue_calls += 1
+        self.key, self.local, self.store = "%s/%d" % (tag, _queue_calls), 0, None
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             from torch.distributed import distributed_c10d as c10d
             self.store = c10d._get_default_store()
@@ -58,9 +65,10 @@ class _Counter:
         return int(self.store.add(self.key, 1)) - 1
 
 
-def run_overlapped(graph, inputs, bandwidth, ramp=0, flags=0, summary=False):
+def run_overlapped(graph, inputs, bandwidth, ramp=0, flags=0, summary=False, gam=False):
     """`inputs` yields (key, (reads, seeds)) or (key, binding.ReadSet); three stages overlap on separate host threads and HIP streams:
-    job building + upload of input k+1, the kernels of input k, download + assembly of input k-1.  Returns [(key, results)]."""
+    job building + upload of input k+1, the kernels of input k, download + assembly of input k-1.  Returns [(key, results)]; results
+    are Python lists, per-read record arrays (summary=True) or the bytes of one GAM group per input (gam=True)."""
     from concurrent.futures import ThreadPoolExecutor
     it = iter(inputs)
 
@@ -83,16 +91,19 @@ def run_overlapped(graph, inputs, bandwidth, ramp=0, flags=0, summary=False):
             key, batch = got
             nxt = pool.submit(prep)                                      # built and uploaded while this input runs
             batch.run()
-            done.append((key, pool.submit(batch.collect, summary)))     # assembled while the next input runs
+            done.append((key, pool.submit(batch.collect_gam) if gam else pool.submit(batch.collect, summary)))     # assembled while the next input runs
         return [(k, f.result()) for k, f in done]
 
 
-def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chunk_reads=65536, tag="ga_queue", summary=False):
+def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chunk_reads=65536, tag="ga_queue", summary=False, gam=False, names=None):
     """every rank calls this with the SAME reads/seeds and its own `graph` (already uploaded to its GPU).  Chunks of reads are pulled
     from a shared counter, so a rank that finishes early takes more; on each rank the stages of consecutive chunks overlap
-    (run_overlapped).  Rank 0 gets the full result list in input order, other ranks get None.  No collective on the data path.
-    summary=True: per-read numpy records (Batch.collect(summary=True)) instead of Python lists, for callers that only count or that
-    read the arrays themselves."""
+    (run_overlapped).  Rank 0 gets the full result in input order, other ranks get None.  No collective on the data path; what travels
+    to rank 0 at the end is, per chunk,
+      summary=True  a numpy record array (Batch.collect(summary=True)), merged into one array in input order;
+      gam=True      the bytes of a GAM group (ga_results_encode_gam): rank 0 returns them joined in chunk order -- GAM groups
+                    concatenate (stream.hpp:24-63), so that is the GAM file of the whole read set, reads ordered longest first;
+      otherwise     Python lists of per-read dicts (tests and small inputs: pickling 200 000 of those is not a transport)."""
     chunks = make_chunks([len(r) for r in reads], chunk_reads)
     counter = _Counter(dist, tag)
     multi = counter.store is not None
@@ -103,15 +114,24 @@ def align_queued(graph, reads, seeds, bandwidth, ramp=0, flags=0, dist=None, chu
             if k >= len(chunks):
                 return
             idx = chunks[k]
-            yield k, ([reads[i] for i in idx], [seeds[i] for i in idx])
+            if gam and names is not None:
+                from . import binding
+                yield k, binding.ReadSet([reads[i] for i in idx], [seeds[i] for i in idx], [names[i] for i in idx])
+            else:
+                yield k, ([reads[i] for i in idx], [seeds[i] for i in idx])
 
-    mine = run_overlapped(graph, taken(), bandwidth, ramp, flags, summary)
+    mine = run_overlapped(graph, taken(), bandwidth, ramp, flags, summary, gam)
     if multi:
-        gathered = [None] * dist.get_world_size()
-        dist.all_gather_object(gathered, mine)
+        gathered = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
         if dist.get_rank() != 0:
             return None
         mine = [kr for part in gathered for kr in part]
+    got = sorted(k for k, _ in mine)
+    if got != list(range(len(chunks))):
+        raise RuntimeError("work queue %s: chunks %s came back for %d chunks" % (counter.key, got[:20], len(chunks)))
+    if gam:
+        return b"".join(res for _, res in sorted(mine, key=lambda kr: kr[0]))
     if summary:
         out = np.zeros(len(reads), dtype=mine[0][1].dtype) if mine else np.zeros(0)
         for k, res in mine:

@@ -62,6 +62,12 @@ void ga_graph_destroy(ga_graph_t* g);
 int ga_graph_add_node(ga_graph_t* g, int64_t digraph_id, const char* seq, size_t len, int reverse_node);
 /* AlignmentGraph::AddEdgeNodeId (AlignmentGraph.cpp:91-106): duplicate edges are ignored */
 int ga_graph_add_edge(ga_graph_t* g, int64_t from_digraph_id, int64_t to_digraph_id);
+/* A FINISHED graph mirrored verbatim: the in- and out-neighbour lists of one node exactly as AlignmentGraph holds them
+ * (inNeighbors[i], outNeighbors[i], AlignmentGraph.h:49-50), digraph ids, before ga_graph_finalize.  Both orders are part of the result
+ * (traceback ties follow inNeighbors, GraphAligner.h:503; the band's heap is fed in outNeighbors order, :1132-1134, 1153-1155), and a
+ * replay of edges grouped by target cannot reproduce both: use this instead of ga_graph_add_edge when copying a built AlignmentGraph.
+ * A node given lists here ignores edges added for it with ga_graph_add_edge. */
+int ga_graph_set_neighbors(ga_graph_t* g, int64_t digraph_id, const int64_t* in_ids, size_t n_in, const int64_t* out_ids, size_t n_out);
 /* the loaders' bidirected -> directed conversion (BigraphToDigraph.cpp:27-56, 58-104):
  * node id -> 2*id (forward) and 2*id+1 (reverse complement); each edge -> two directed edges */
 int ga_graph_add_bigraph_node(ga_graph_t* g, int64_t id, const char* seq, size_t len);
@@ -129,14 +135,19 @@ typedef struct ga_read_result {
 	uint64_t column_updates;                /* band columns computed for this read (first pass) */
 } ga_read_result_t;
 
+/* The three arrays behind `reads` are written by several host threads at places fixed before the lengths are known, so they have GAPS:
+ * n_mappings / n_edit_bytes / n_trace are the arrays' extents, not counts of valid entries, and the bytes between one read's entries
+ * and the next's are unspecified (recycled memory).  Valid entries are exactly those a read's record points at:
+ * mappings[first_mapping .. first_mapping + n_mappings), trace[first_trace .. first_trace + n_trace), and per mapping
+ * edit_bytes[edit_seq_off .. edit_seq_off + to_length).  Never iterate an array from 0 to its extent. */
 typedef struct ga_results {
 	size_t n_reads;
 	const ga_read_result_t* reads;
-	size_t n_mappings;
+	size_t n_mappings;                      /* extent of `mappings` (see above) */
 	const ga_mapping_t* mappings;
-	size_t n_edit_bytes;
+	size_t n_edit_bytes;                    /* extent of `edit_bytes` */
 	const char* edit_bytes;
-	size_t n_trace;
+	size_t n_trace;                         /* extent of `trace` */
 	const ga_trace_item_t* trace;
 } ga_results_t;
 
@@ -152,6 +163,10 @@ int ga_results_unsplit(const ga_graph_t* g, const ga_results_t* in, ga_results_t
 /* staged form of the same call, for callers that keep inputs resident in HBM and for measurement:
  *   prepare = validate seeds, build extension jobs, upload reads;  run = the device work only;
  *   collect = download + assemble AlignmentResults. */
+/* Threading: a graph is read-only once uploaded and may serve any number of batches from any threads.  One batch is used by one thread
+ * at a time (prepare -> run -> collect may run on three different threads, as the overlapped pipeline does, but never concurrently on
+ * the same batch).  Batches of one graph that RUN concurrently do not share scratch: the first takes the graph's pool, the others
+ * allocate their own for the duration. */
 typedef struct ga_batch ga_batch_t;
 int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t n_reads, const ga_seed_t* seeds, const size_t* seed_offsets,
                      int initial_bandwidth, int ramp_bandwidth, uint32_t flags, ga_batch_t** out);

@@ -118,6 +118,7 @@ struct EmulBatch : GaBackendBatch
 		uint64_t totalRows = 0;
 		for (auto& j : jobs) totalRows += j.n_rows;
 		pool.assign(totalRows * 3 + 4096 * jobs.size() + 64, 0);
+		if (const char* t = getenv("GA_TEST_TRACE_POOL_BYTES")) pool.assign((size_t)atoll(t) & ~(size_t)3, 0);
 		poolTop = 0;
 		retried = 0;
 		// first pass: the lanes = reads program, groups of 64 jobs (longest first, as the device queue hands them out), with

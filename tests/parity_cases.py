@@ -387,3 +387,24 @@ def case_sparse_sharp_edges(lib_path=None):
     # ... and a seed ON that node without a ramp width: bandwidth 0 again
     devs, oras = pc.check_parity(nodes, edges, [synth.add_errors(contig[5000:6500], 0.03, 0.03, 0.03, rng).tobytes().decode()], [(3, 0, False)], 35, ramp=0, lib_path=lib_path, ctx="seed on a 209 kbp node")
     assert oras[0]["status"] == 1 and devs[0]["status"] == 1
+
+
+def case_trace_pool_overflow(lib_path=None, monkeypatch=None):
+    """a trace pool far too small for the batch: jobs that find no room report a capacity miss; every job that reports success has
+    its moves intact (claims commit only when they fit, so no two regions overlap) and equals the oracle"""
+    import os
+    g = synth.linear_graph(60000, node_len=64, seed=5)
+    reads, seeds = synth.simulate_reads(g, 96, 1500, seed=21)
+    os.environ["GA_TEST_TRACE_POOL_BYTES"] = str(40000)
+    try:
+        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, 35, lib_path=lib_path)
+    finally:
+        del os.environ["GA_TEST_TRACE_POOL_BYTES"]
+    n_ok = n_cap = 0
+    for i, (d, o) in enumerate(zip(devs, oras)):
+        if d["status"] == 10:
+            n_cap += 1
+            continue
+        pc.compare_read(d, o, "small trace pool, read %d" % i)
+        n_ok += 1
+    assert n_ok >= 8 and n_cap >= 8, (n_ok, n_cap)

@@ -75,3 +75,7 @@ def test_sparse_method_and_override(lib, branches, branch_len, shared, stem, bw,
 
 def test_sparse_sharp_edges(lib):
     cases.case_sparse_sharp_edges(lib)
+
+
+def test_trace_pool_overflow(lib):
+    cases.case_trace_pool_overflow(lib)

@@ -110,3 +110,7 @@ def test_randomised_campaign():
     stats = json.loads(out.stdout.strip().split("\n")[-1])
     assert stats["mismatches"] == 0, stats
     assert stats["compared"] >= 300
+
+
+def test_trace_pool_overflow():
+    cases.case_trace_pool_overflow()
