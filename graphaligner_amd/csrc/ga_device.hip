@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 	using namespace gal;
 	__shared__ uint32_t lds[Lay<N>::WORDS * LW + LW * kStageWords64 * 2];      // tables, then the staging image of LW lanes
 	const int lane = (int)threadIdx.x;
-	const WaveLayout lay = wave_layout<N>(L.cap_cols, L.cap_rows, L.max_slices, L.cap_moves);
+	const WaveLayout lay = wave_layout<N>(L.cap_cols, L.cap_rows, L.max_slices, L.cap_moves, LW);
 	uint8_t* base = L.scratch + (uint64_t)blockIdx.x * L.wave_bytes;
 	while (true)
 	{
@@ -96,16 +96,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 		const bool hasJob = lane < (int)L.lanes_per_wave && lane < LW && first + (uint32_t)lane < L.n_jobs;
 		const uint32_t jobIndex = hasJob ? (L.job_list ? L.job_list[first + (uint32_t)lane] : (uint32_t)(first + (uint32_t)lane)) : 0u;
 		LaneMem m;
-		m.lane = lane;
+		m.lane = lane < LW ? lane : 0;      // (lanes beyond the variant's LW carry no job: they shadow lane 0's addresses and store nothing)
+		m.tid = lane;
+		m.ls = LW;
 		m.lds.base = lds + (lane < LW ? lane : 0);
 		m.lds.lw = LW;
 		m.stage = (uint64_t*)(lds + Lay<N>::WORDS * LW);
 		m.usedChunks = 12u * (L.lanes_per_wave < (uint32_t)LW ? L.lanes_per_wave : (uint32_t)LW);
-		m.endPrev = (uint32_t*)(base + lay.endA) + lane;
-		m.endCur = (uint32_t*)(base + lay.endB) + lane;
-		m.hdr = (uint32_t*)(base + lay.hdr) + lane;
-		m.snodes = (uint32_t*)(base + lay.snodes) + lane;
-		m.moves = (uint32_t*)(base + lay.moves) + lane;
+		m.endPrev = (uint32_t*)(base + lay.endA) + m.lane;
+		m.endCur = (uint32_t*)(base + lay.endB) + m.lane;
+		m.hdr = (uint32_t*)(base + lay.hdr) + m.lane;
+		m.snodes = (uint32_t*)(base + lay.snodes) + m.lane;
+		m.moves = (uint32_t*)(base + lay.moves) + m.lane;
 		m.arena = base + lay.arena;
 		LaneState st;
 #if GA_STAMPS == 3
@@ -390,7 +392,7 @@ struct DevBatch : GaBackendBatch
 		P.cap_rows = (P.max_slices * rowsPerSlice + 64 + 7u) & ~7u;               // (whole blocks of 8 rows: the block behind them is the spare one)
 		// (node runs are five words each and a path can change node at every row: the staging plane holds one run per row then)
 		P.cap_moves = cfg.emit_runs ? maxRows * 20 + 1024 : maxRows * 2 + 1024;
-		const gal::WaveLayout lay = gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves);
+		const gal::WaveLayout lay = gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves, LW);
 		P.wave_bytes = lay.bytes;
 		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + LW * gal::kStageWords64 * 8;
 		const uint32_t wavesPerCu = std::max<uint32_t>(1, std::min<uint32_t>(8, 163840u / ldsBytes));
@@ -519,8 +521,10 @@ struct DevBatch : GaBackendBatch
 				if (!first && list.size() < 512) break;
 				// (10 / 24 / 56 band nodes per lane = 4 / 2 / 1 waves per CU next to the 12.8 KB block image)
 				if (n == 0) rc = lanesPass<10, 64>(list, 400, first);
-				else if (n == 1) rc = lanesPass<24, 64>(list, 1024, first);
-				else rc = lanesPass<56, 64>(list, 2560, first);
+				// (the wider tables trade lanes for LDS per lane: 32 and 16 lanes per wave keep four waves on every CU -- the same number of
+				// reads in flight as 64-lane waves that leave three SIMDs of four idle, in four times as many instruction streams)
+				else if (n == 1) rc = lanesPass<24, 32>(list, 1024, first);
+				else rc = lanesPass<56, 16>(list, 2560, first);
 				first = false;
 				std::vector<uint32_t> again;
 				for (uint32_t i : list) if (widerLanes(outs[i].status)) again.push_back(i);
@@ -534,10 +538,13 @@ struct DevBatch : GaBackendBatch
 		if (!useLanes)
 		{
 			// the lean wave-per-read variant over everything (32 band nodes in LDS, 24 waves per CU)
-			rc = retryPass<32, false>(4096, 3 * 64 + 5 * 800, 2, 24, true, false);
+#ifndef GA_FIRST_N
+#define GA_FIRST_N 32
+#endif
+			rc = retryPass<GA_FIRST_N, false>(4096, 3 * 64 + 5 * 800, 2, 24, true, false);
 			if (rc) return rc;
 			st.main_ms = st.kernel_ms;
-			st.main_variant = -32;                         // (negative: the wave-per-read kernel with that many band nodes in LDS)
+			st.main_variant = -GA_FIRST_N;                 // (negative: the wave-per-read kernel with that many band nodes in LDS)
 			st.jobs_retried = 0;
 		}
 		rc = retryPass<64, false>(8192, 3 * 64 + 5 * 2048, 3, 12, true, false);

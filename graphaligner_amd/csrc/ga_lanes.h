@@ -85,25 +85,27 @@ inline
 #ifndef GA_EMULATE
 __host__ __device__
 #endif
-WaveLayout wave_layout(uint32_t capCols, uint32_t capRows, uint32_t maxSlices, uint32_t capMoves)
+WaveLayout wave_layout(uint32_t capCols, uint32_t capRows, uint32_t maxSlices, uint32_t capMoves, uint32_t ls = 64)
 {
+	// ls = lane stride of the planes = how many lanes of a wave carry jobs (64, or fewer in the variants that trade lanes for LDS per lane)
 	auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
 	WaveLayout l;
 	uint64_t at = 0;
-	l.endA = at; at = up(at + 256ull * (capCols + 64));     // (+ slack: operands are requested up to two chunks past a node's end)
-	l.endB = at; at = up(at + 256ull * (capCols + 64));
-	l.hdr = at; at = up(at + 256ull * kHdrWords * (maxSlices + 1));
-	l.snodes = at; at = up(at + 256ull * 2 * N * (maxSlices + 2));
-	l.moves = at; at = up(at + 256ull * ((capMoves + 3) / 4 + 16));
-	l.arena = at; at = up(at + (uint64_t)kRecBytes * 64 * (capRows + 16));
+	const uint64_t row = 4ull * ls;
+	l.endA = at; at = up(at + row * (capCols + 64));     // (+ slack: operands are requested up to two chunks past a node's end)
+	l.endB = at; at = up(at + row * (capCols + 64));
+	l.hdr = at; at = up(at + row * kHdrWords * (maxSlices + 1));
+	l.snodes = at; at = up(at + row * 2 * N * (maxSlices + 2));
+	l.moves = at; at = up(at + row * ((capMoves + 3) / 4 + 16));
+	l.arena = at; at = up(at + (uint64_t)kRecBytes * ls * (capRows + 16));
 	l.bytes = at;
 	return l;
 }
 
 // where the record of (arena row, lane) lives: blocks of R consecutive rows of one lane are contiguous
-template <int R> GAL_FN uint64_t rec_off(uint32_t row, int lane)
+template <int R> GAL_FN uint64_t rec_off(uint32_t row, int lane, uint32_t ls)
 {
-	return ((uint64_t)(row / R) * 64 + (uint32_t)lane) * (R * kRecBytes) + (uint64_t)(row % R) * kRecBytes;
+	return ((uint64_t)(row / R) * ls + (uint32_t)lane) * (R * kRecBytes) + (uint64_t)(row % R) * kRecBytes;
 }
 
 // ---- per-lane LDS tables: word i of lane l sits at lds[i * LW + l] ------------------------------------------------
@@ -163,6 +165,9 @@ struct LaneMem
 	uint64_t* stage;              // device: the wave's LDS image of the open block of 8 arena rows
 	uint32_t usedChunks;          // device: 16-byte chunks of a block image that belong to lanes with a job (12 per lane)
 	int lane;
+	int tid;                      // device: the thread's index in the wave (= lane, except in the variants where only the first `ls` lanes carry jobs
+	                              // and the others shadow lane 0: every thread still takes part in the block flush)
+	uint32_t ls;                  // lane stride of the planes and of the arena's blocks (a constant of the kernel variant: 64, 32 or 16)
 };
 
 // what a lane carries from slice to slice
@@ -640,12 +645,12 @@ GAL_FN int col_value(uint64_t vp, uint64_t vn, int before, int row)            /
 // (records are 8-byte aligned: three 64-bit words)
 template <int R> GAL_FN void rec_store(const LaneMem& m, uint32_t row, const Col& c, uint32_t endWord)
 {
-	uint64_t* p = (uint64_t*)(m.arena + rec_off<R>(row, m.lane));
+	uint64_t* p = (uint64_t*)(m.arena + rec_off<R>(row, m.lane, m.ls));
 	p[0] = c.vp; p[1] = c.vn; p[2] = (uint64_t)(uint32_t)c.before | ((uint64_t)endWord << 32);
 }
 template <int R> GAL_FN void rec_load(const LaneMem& m, uint32_t row, Col& c, uint32_t& endWord)
 {
-	const uint64_t* p = (const uint64_t*)(m.arena + rec_off<R>(row, m.lane));
+	const uint64_t* p = (const uint64_t*)(m.arena + rec_off<R>(row, m.lane, m.ls));
 	c.vp = p[0];
 	c.vn = p[1];
 	const uint64_t t = p[2];
@@ -656,7 +661,7 @@ template <int R> GAL_FN void rec_load(const LaneMem& m, uint32_t row, Col& c, ui
 // then has to wait for the request before it may write to it)
 template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c)
 {
-	const uint64_t* p = (const uint64_t*)(m.arena + rec_off<R>(row, m.lane));
+	const uint64_t* p = (const uint64_t*)(m.arena + rec_off<R>(row, m.lane, m.ls));
 	c.vp = p[0];
 	c.vn = p[1];
 	c.before = (int)((const uint32_t*)p)[4];
@@ -668,15 +673,15 @@ template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c
 template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t block, uint32_t spareBlock)
 {
 	__builtin_amdgcn_wave_barrier();
-	uint8_t* dst = m.arena + (uint64_t)block * (64 * 8 * kRecBytes);
+	uint8_t* dst = m.arena + (uint64_t)block * (m.ls * 8 * kRecBytes);
 	// the part of lanes that carry no job (a batch spread over more waves than it fills) goes to a spare block behind the arena's
 	// rows instead: the same few lines over and over, which the L2 absorbs -- the stores stay unconditional, HBM sees the used part
-	uint8_t* spare = m.arena + (uint64_t)spareBlock * (64 * 8 * kRecBytes);
+	uint8_t* spare = m.arena + (uint64_t)spareBlock * (m.ls * 8 * kRecBytes);
 	// (a kernel whose waves carry LW < 64 jobs stages, and writes back, only those lanes' part of the block)
 #pragma unroll
 	for (int j = 0; j < 12 * LW / 64; j++)
 	{
-		const uint32_t q = (uint32_t)m.lane + 64u * (uint32_t)j;
+		const uint32_t q = (uint32_t)m.tid + 64u * (uint32_t)j;
 		const uint32_t ln = q / 12u, part = q % 12u;
 		const uint64_t* sp = m.stage + ln * 25 + part * 2;
 		const uint64_t a = sp[0], b = sp[1];
@@ -745,7 +750,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 		const uint32_t* rec2 = g_rec(g, o >= 0 ? l.rd(LY::C_NODE + s2) : 0u);
 		nFirstLo = rec2[0]; nFirstHi = rec2[1];
 		const uint32_t pinfo2 = o >= 0 ? l.rd(LY::C_PINFO + s2) : (kNone << 16);
-		nPend0 = m.endPrev[(uint64_t)((pinfo2 >> 16) != kNone ? (pinfo2 & 0xffffu) : 0u) * 64];
+		nPend0 = m.endPrev[(uint64_t)((pinfo2 >> 16) != kNone ? (pinfo2 & 0xffffu) : 0u) * m.ls];
 	};
 	request(ord);
 	// the node finished last: its last column stays in c / exists
@@ -790,7 +795,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 		const uint32_t pend0raw = nPend0;
 		request(ord - 1);
 		const bool aboveAlways = j0 && inPrev;                                   // "previousEq" (:1503): raw char ==, not characterMatch
-		const uint32_t* pend = m.endPrev + (uint64_t)pbase * 64;
+		const uint32_t* pend = m.endPrev + (uint64_t)pbase * m.ls;
 		static_assert(U == 8, "a chunk is one block of 8 arena rows");
 		const uint32_t nChunks = (wave_max(len) + U - 1) / U;                    // the wave's nodes go in chunks of U columns = blocks of U arena rows
 		if (tick + nChunks * U + U > capRows) { if (act) status = GA_CAP_ARENA; ord = -1; break; }
@@ -803,7 +808,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 		uint32_t pe[U];
 		uint64_t bw;
 #pragma unroll
-		for (int i = 0; i < U; i++) pe[i] = pendSafe[(uint64_t)i * 64];
+		for (int i = 0; i < U; i++) pe[i] = pendSafe[(uint64_t)i * m.ls];
 		bw = (uint64_t)seqSafe[0] | ((uint64_t)seqSafe[1] << 32);
 		int nodeMin = INF, zero = 0, above2 = 0;
 		uint32_t endWord = 0;
@@ -816,7 +821,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 				nodeMin = end < nodeMin ? end : nodeMin;
 				if (end <= sliceMin) { sliceMin = end; minSlot = s; minOffset = w; }  // the LAST column attaining the minimum (:1551-1559, 2410-2418)
 			}
-			m.endCur[(uint64_t)(on ? colBase + w : dummyCol) * 64] = endWord;
+			m.endCur[(uint64_t)(on ? colBase + w : dummyCol) * m.ls] = endWord;
 			put(on, t0 + w, slot, c, endWord);
 		};
 		if (act)
@@ -907,7 +912,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 			uint32_t pe2[U];
 			uint64_t bw2;
 #pragma unroll
-			for (int i = 0; i < U; i++) pe2[i] = pendSafe[(uint64_t)(w0 + U + (uint32_t)i) * 64];
+			for (int i = 0; i < U; i++) pe2[i] = pendSafe[(uint64_t)(w0 + U + (uint32_t)i) * m.ls];
 			{ const uint32_t* q = seqSafe + (((sh0 >> 1) + w0 + U) >> 4); bw2 = (uint64_t)q[0] | ((uint64_t)q[1] << 32); }
 #pragma unroll
 			for (int i = 0; i < U; i++)
@@ -993,7 +998,7 @@ template <int N> GAL_FN void lane_begin(const GaLanesLaunch& L, const LaneMem& m
 	m.lds.wr(LY::P_NODE, job.seed_node);
 	m.lds.wr(LY::P_END, 0u | 4u);
 	m.lds.wr(LY::P_PACK, 0);
-	for (uint32_t c = 0; c < seedLen; c++) m.endPrev[(uint64_t)c * 64] = 4u;       // score 0, scoreEndExists
+	for (uint32_t c = 0; c < seedLen; c++) m.endPrev[(uint64_t)c * m.ls] = 4u;       // score 0, scoreEndExists
 	st.pn = 1;
 	st.live = true;
 }
@@ -1044,16 +1049,16 @@ template <int N> GAL_FN void lane_end_slice(const GaLanesLaunch& L, LaneMem& m, 
 	if (!currentlyCorrect && st.rampUntil < slice && rampPossible) { st.status = GA_UNSUPPORTED_RAMP; st.live = false; return; }   // the redo (:2648-2719) is the ladder's
 	// the slice is kept: header and node list for the traceback
 	const int cn = st.cn;
-	uint32_t* h = m.hdr + (uint64_t)slice * kHdrWords * 64;
-	h[0] = (uint32_t)cn; h[64] = st.totalCols; h[128] = (uint32_t)st.sliceMin; h[192] = (uint32_t)st.minSlot; h[256] = st.minOffset;
-	h[320] = (uint32_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0));
-	h[384] = 0;                                                                   // (node rows below are absolute)
-	uint32_t* sn = m.snodes + (uint64_t)slice * 2 * N * 64;
+	uint32_t* h = m.hdr + (uint64_t)slice * kHdrWords * m.ls;
+	h[0] = (uint32_t)cn; h[1 * m.ls] = st.totalCols; h[2 * m.ls] = (uint32_t)st.sliceMin; h[3 * m.ls] = (uint32_t)st.minSlot; h[4 * m.ls] = st.minOffset;
+	h[5 * m.ls] = (uint32_t)((currentlyCorrect ? 1 : 0) | (falseFromCorrect ? 2 : 0));
+	h[6 * m.ls] = 0;                                                                   // (node rows below are absolute)
+	uint32_t* sn = m.snodes + (uint64_t)slice * 2 * N * m.ls;
 	for (int k = 0; k < cn; k++)
 	{
 		const uint32_t node = l.rd(LY::C_NODE + k), geo = l.rd(LY::C_GEO + k);
-		sn[(uint64_t)(2 * k) * 64] = node;
-		sn[(uint64_t)(2 * k + 1) * 64] = l.rd(LY::C_PINFO + k);                       // arena row of the node's column 0
+		sn[(uint64_t)(2 * k) * m.ls] = node;
+		sn[(uint64_t)(2 * k + 1) * m.ls] = l.rd(LY::C_PINFO + k);                       // arena row of the node's column 0
 		// ... and the slice becomes the state the next one is computed from
 		l.wr(LY::P_NODE + k, node);
 		l.wr(LY::P_END + k, l.rd(LY::C_END + k));
@@ -1067,6 +1072,47 @@ template <int N> GAL_FN void lane_end_slice(const GaLanesLaunch& L, LaneMem& m, 
 	st.prevMin = st.sliceMin;
 	uint32_t* t = m.endPrev; m.endPrev = m.endCur; m.endCur = t;
 }
+
+#ifndef GA_EMULATE
+// claim `bytes` of the pool for every lane that calls (the callers are the active lanes of one wave, converged): true + offset when it fit
+GAL_FN uint64_t claim_cas(uint64_t* top, uint64_t cap, uint64_t bytes)
+{
+	unsigned long long seen = *(volatile unsigned long long*)top;
+	while (seen + bytes <= cap)
+	{
+		const unsigned long long prev = atomicCAS((unsigned long long*)top, seen, seen + (unsigned long long)bytes);
+		if (prev == seen) return seen;
+		seen = prev;
+	}
+	return ~0ull;
+}
+GAL_FN bool claim_for_wave(uint64_t* top, uint64_t cap, uint64_t bytes, uint64_t& at)
+{
+	const uint64_t active = __ballot(1);
+	const int lane = (int)(threadIdx.x & 63);
+	// exclusive prefix of `bytes` over the active lanes, and the wave's total
+	uint64_t before = 0, total = 0;
+	for (uint64_t m = active; m; m &= m - 1)
+	{
+		const int src = __builtin_ctzll(m);
+		const uint64_t b = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(bytes >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bytes, src, 64);
+		if (src < lane) before += b;
+		total += b;
+	}
+	const int leader = __builtin_ctzll(active);
+	uint64_t base = ~0ull;
+	if (lane == leader) base = claim_cas(top, cap, total);
+	base = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(base >> 32), leader, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, leader, 64);
+	if (base != ~0ull) { at = base + before; return true; }
+	// the wave's total does not fit: lane by lane, whatever still does
+	bool ok = false;
+	for (uint64_t m = active; m; m &= m - 1)
+	{
+		if (lane == __builtin_ctzll(m)) { const uint64_t a = claim_cas(top, cap, bytes); if (a != ~0ull) { at = a; ok = true; } }
+	}
+	return ok;
+}
+#endif
 
 // ---- traceback (getTraceFromTable :894-957 with pickBacktracePredecessor :493-591) and the job's output ----------
 template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& m, LaneState& st, bool hasJob)
@@ -1085,12 +1131,12 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 	uint32_t kept = st.nPushed;
 	if (status == GA_OK && kept > 0)
 	{
-		bool ok = (m.hdr[((uint64_t)(kept - 1) * kHdrWords + 5) * 64] & 1u) != 0;
+		bool ok = (m.hdr[((uint64_t)(kept - 1) * kHdrWords + 5) * m.ls] & 1u) != 0;
 		while (!ok)
 		{
 			kept--;
 			if (kept == 0) break;
-			ok = (m.hdr[((uint64_t)(kept - 1) * kHdrWords + 5) * 64] & 2u) != 0;
+			ok = (m.hdr[((uint64_t)(kept - 1) * kHdrWords + 5) * m.ls] & 2u) != 0;
 		}
 	}
 	out.n_valid = status == GA_OK ? kept : 0;
@@ -1103,24 +1149,24 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		uint32_t aN = 0, aRow = 0;                                                // header of the slice two above, requested one slice change ahead
 		int tCN = LY::T_CN, tCB = LY::T_CB, tPN = LY::T_PN, tPB = LY::T_PB;
 		auto loadHeader = [&](uint32_t sl, uint32_t& count, uint32_t& rowBase) {
-			const uint32_t* h = m.hdr + (uint64_t)sl * kHdrWords * 64;
+			const uint32_t* h = m.hdr + (uint64_t)sl * kHdrWords * m.ls;
 			count = h[0];
-			rowBase = h[384];
+			rowBase = h[6 * m.ls];
 		};
 		auto loadTable = [&](int tn, int tb, uint32_t sl, uint32_t count) {
-			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * 64;
+			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * m.ls;
 			for (uint32_t k = 0; k < count; k += 4)
 			{
 				uint32_t a[8];
 #pragma unroll
-				for (int i = 0; i < 8; i++) a[i] = sn[(uint64_t)(2 * k + (uint32_t)i) * 64];      // (rows past `count` are inside the plane)
+				for (int i = 0; i < 8; i++) a[i] = sn[(uint64_t)(2 * k + (uint32_t)i) * m.ls];      // (rows past `count` are inside the plane)
 #pragma unroll
 				for (int i = 0; i < 4; i++) if (k + (uint32_t)i < count) { l.wr(tn + (int)k + i, a[2 * i]); l.wr(tb + (int)k + i, a[2 * i + 1]); }
 			}
 		};
 		auto loadTableFrom = [&](int tn, int tb, uint32_t sl, uint32_t count, uint32_t from) {
-			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * 64;
-			for (uint32_t k = from; k < count; k++) { const uint32_t a0 = sn[(uint64_t)(2 * k) * 64], a1 = sn[(uint64_t)(2 * k + 1) * 64]; l.wr(tn + (int)k, a0); l.wr(tb + (int)k, a1); }
+			const uint32_t* sn = m.snodes + (uint64_t)sl * 2 * N * m.ls;
+			for (uint32_t k = from; k < count; k++) { const uint32_t a0 = sn[(uint64_t)(2 * k) * m.ls], a1 = sn[(uint64_t)(2 * k + 1) * m.ls]; l.wr(tn + (int)k, a0); l.wr(tb + (int)k, a1); }
 		};
 		// what the traceback keeps of a node's graph record: first column, in-degree, first four in-neighbours with their lengths
 		struct NodeRec { uint64_t firstCol; uint32_t inDeg; uint32_t nb[4], nbLen[4]; };
@@ -1136,10 +1182,10 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		if (sIdx > 1) loadHeader(sIdx - 2, aN, aRow);
 		loadTable(tCN, tCB, sIdx, nN);
 		if (sIdx > 0) loadTable(tPN, tPB, sIdx - 1, pN);
-		const uint32_t* h = m.hdr + (uint64_t)sIdx * kHdrWords * 64;
-		out.score = (int32_t)h[128];
-		uint32_t node = l.rd(tCN + (int)h[192]);
-		uint32_t offset = h[256];
+		const uint32_t* h = m.hdr + (uint64_t)sIdx * kHdrWords * m.ls;
+		out.score = (int32_t)h[2 * m.ls];
+		uint32_t node = l.rd(tCN + (int)h[3 * m.ls]);
+		uint32_t offset = h[4 * m.ls];
 		uint32_t row = sIdx * W + (W - 1);
 		out.start_node = node; out.start_offset = offset; out.start_row = row;
 		// node runs instead of moves (L.emit_runs): a run is opened at the first cell met in a node (its last cell on the read) once
@@ -1152,8 +1198,8 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		bool started = row < traceRows;
 		auto emitRun = [&](uint32_t n, uint32_t firstOff, uint32_t firstRow) {
 			if (5 * (nRuns + 1) > capRunWords) { status = GA_CAP_TRACE; tracing = false; return; }
-			uint32_t* d = m.moves + (uint64_t)(5 * nRuns) * 64;
-			d[0] = n; d[64] = firstOff; d[128] = firstRow; d[192] = runLastOff; d[256] = runLastRow;
+			uint32_t* d = m.moves + (uint64_t)(5 * nRuns) * m.ls;
+			d[0] = n; d[1 * m.ls] = firstOff; d[2 * m.ls] = firstRow; d[3 * m.ls] = runLastOff; d[4 * m.ls] = runLastRow;
 			nRuns++;
 		};
 		uint64_t e[4];
@@ -1196,7 +1242,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			if (emitRuns) return;
 			const uint32_t code = res == 1 ? GA_MOVE_LEFT : res == 2 ? GA_MOVE_DIAG : GA_MOVE_UP;
 			pack |= (code | (res == 3 ? 0u : ((uint32_t)via << 2))) << (8 * (len & 3));
-			if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * 64] = pack; pack = 0; }
+			if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * m.ls] = pack; pack = 0; }
 			len++;
 		};
 		// after a change of node or slice: where the node's columns are, its graph record; and the window, whenever it does not reach
@@ -1543,11 +1589,11 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				uint64_t ne[4] = {0, 0, 0, 0};
 				{
 					// the slice above the new one: the first four entries of its node list here, the rest (wide bands) in the loop below
-					const uint32_t* sn = m.snodes + (uint64_t)(changed && sIdx > 0 ? sIdx - 1 : 0) * 2 * N * 64;
+					const uint32_t* sn = m.snodes + (uint64_t)(changed && sIdx > 0 ? sIdx - 1 : 0) * 2 * N * m.ls;
 #pragma unroll
-					for (int i = 0; i < 8; i++) tbl[i] = sn[(uint64_t)i * 64];
-					const uint32_t* h = m.hdr + (uint64_t)(changed && sIdx > 1 ? sIdx - 2 : 0) * kHdrWords * 64;
-					hN = h[0]; hRow = h[384];
+					for (int i = 0; i < 8; i++) tbl[i] = sn[(uint64_t)i * m.ls];
+					const uint32_t* h = m.hdr + (uint64_t)(changed && sIdx > 1 ? sIdx - 2 : 0) * kHdrWords * m.ls;
+					hN = h[0]; hRow = h[6 * m.ls];
 					const uint64_t* q = st.eq + (uint64_t)(changed ? sIdx : 0) * 5;
 					ne[0] = q[0]; ne[1] = q[1]; ne[2] = q[2]; ne[3] = q[3];
 				}
@@ -1601,28 +1647,22 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		}
 #undef GAL_ANY
 		{ const uint64_t t2 = lap_clock(); st.laps[1] += t2 - lapT; lapT = t2; }
-		if (!emitRuns && (len & 3)) m.moves[(uint64_t)(len >> 2) * 64] = pack;
+		if (!emitRuns && (len & 3)) m.moves[(uint64_t)(len >> 2) * m.ls] = pack;
 		st.laps[3] = lap_clock();
 		// hand the moves (or runs) over: claim their bytes (rounded to words) of the pool and copy them
 		if (status == GA_OK)
 		{
 			const uint32_t words = emitRuns ? 5 * nRuns : (len + 3) / 4;
 			// the claim only ever commits when it fits (compare-and-swap): an overshoot that is rolled back later could leave the pool's
-			// top below a region another lane claimed in between
+			// top below a region another lane claimed in between.  The lanes of a wave get here together: one of them claims for all
+			// (a compare-and-swap per lane on one address is tens of thousands of lanes retrying against each other), and only a wave
+			// whose total does not fit falls back to lane-by-lane claims.
 			uint64_t at = 0;
 			bool claimed = false;
 #ifdef GA_EMULATE
 			if (*L.trace_top + (uint64_t)words * 4 <= L.trace_pool_cap) { at = *L.trace_top; *L.trace_top += (uint64_t)words * 4; claimed = true; }
 #else
-			{
-				unsigned long long seen = *(volatile unsigned long long*)L.trace_top;
-				while (seen + (unsigned long long)words * 4 <= L.trace_pool_cap)
-				{
-					const unsigned long long prev = atomicCAS((unsigned long long*)L.trace_top, seen, seen + (unsigned long long)words * 4);
-					if (prev == seen) { at = seen; claimed = true; break; }
-					seen = prev;
-				}
-			}
+			claimed = claim_for_wave(L.trace_top, L.trace_pool_cap, (uint64_t)words * 4, at);
 #endif
 			if (!claimed) status = GA_CAP_TRACE;
 			else
@@ -1632,7 +1672,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				{
 					uint32_t a[8];
 #pragma unroll
-					for (int i = 0; i < 8; i++) a[i] = m.moves[(uint64_t)(k + (uint32_t)i) * 64];     // (the staging plane has a row of slack past `words`)
+					for (int i = 0; i < 8; i++) a[i] = m.moves[(uint64_t)(k + (uint32_t)i) * m.ls];     // (the staging plane has a row of slack past `words`)
 #pragma unroll
 					for (int i = 0; i < 8; i++) if (k + (uint32_t)i < words) dst[k + (uint32_t)i] = a[i];
 				}

@@ -83,7 +83,7 @@ struct EmulBatch : GaBackendBatch
 		for (int lane = 0; lane < 64; lane++)
 		{
 			LaneMem& m = mem[lane];
-			m.lane = lane;
+			m.lane = lane; m.tid = lane; m.ls = 64;
 			m.lds.base = lds.data() + lane; m.lds.lw = 64;
 			m.endPrev = (uint32_t*)(scratch.data() + lay.endA) + lane;
 			m.endCur = (uint32_t*)(scratch.data() + lay.endB) + lane;
