@@ -84,7 +84,7 @@ template <int N, int LW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) ga_lanes_kernel(gal::GaLanesLaunch L)
 {
 	using namespace gal;
-	__shared__ uint32_t lds[Lay<N>::WORDS * LW + LW * kStageWords64 * 2];      // tables, then the staging image of LW lanes
+	__shared__ uint32_t lds[Lay<N>::WORDS * LW + LW * kStageWords64 * 2 + 64];  // tables, the staging image of LW lanes, the lanes' arena blocks
 	const int lane = (int)threadIdx.x;
 	const WaveLayout lay = wave_layout<N>(L.cap_cols, L.cap_rows, L.max_slices, L.cap_moves, LW);
 	uint8_t* base = L.scratch + (uint64_t)blockIdx.x * L.wave_bytes;
@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 		m.lds.base = lds + (lane < LW ? lane : 0);
 		m.lds.lw = LW;
 		m.stage = (uint64_t*)(lds + Lay<N>::WORDS * LW);
+		m.laneBlocks = lds + Lay<N>::WORDS * LW + LW * kStageWords64 * 2;
 		m.usedChunks = 12u * (L.lanes_per_wave < (uint32_t)LW ? L.lanes_per_wave : (uint32_t)LW);
 		m.endPrev = (uint32_t*)(base + lay.endA) + m.lane;
 		m.endCur = (uint32_t*)(base + lay.endB) + m.lane;
@@ -116,13 +117,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 		uint64_t tA = gaw::stamp(), tB, acc[4] = {0, 0, 0, 0};
 #define GAL_LAP(i) do { tB = gaw::stamp(); acc[i] += tB - tA; tA = tB; } while (0)
 		lane_begin<N>(L, m, st, jobIndex, hasJob);
-		uint32_t rowTop = 0;                               // wave-uniform: one arena row per step of the wave
+		uint32_t blockTop = 0;                             // wave-uniform: the arena's next free block of 8 rows
 		for (uint32_t slice = 0; ; slice++)
 		{
 			lane_band<N>(L, m, st, slice);
 			GAL_LAP(0);
 			if (!__ballot(st.live)) break;
-			fill_slice<N, 8, LW>(L.graph, m, st, slice, st.live, rowTop, L.cap_rows, L.cap_cols);
+			fill_slice<N, 8, LW>(L.graph, m, st, slice, st.live, blockTop, L.cap_rows, L.cap_cols);
 			GAL_LAP(1);
 			lane_end_slice<N>(L, m, st, slice);
 			GAL_LAP(2);
@@ -285,7 +286,8 @@ struct DevBatch : GaBackendBatch
 	int init(const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobsIn)
 	{
 		HIP_OK(hipSetDevice(g->device));
-		HIP_OK(hipStreamCreate(&stream));
+		// (non-blocking: a copy or a kernel of this batch must not wait for another batch's kernel through the null stream)
+		HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 		HIP_OK(hipEventCreate(&evA));
 		HIP_OK(hipEventCreate(&evB));
 		jobs = jobsIn;
@@ -389,21 +391,28 @@ struct DevBatch : GaBackendBatch
 		for (uint32_t i : list) maxRows = std::max(maxRows, jobs[i].n_rows);
 		P.max_slices = std::max<uint32_t>(maxRows / 64, 1);
 		P.cap_cols = std::min<uint32_t>(N * 256u, 0xff00u);
-		P.cap_rows = (P.max_slices * rowsPerSlice + 64 + 7u) & ~7u;               // (whole blocks of 8 rows: the block behind them is the spare one)
-		// (node runs are five words each and a path can change node at every row: the staging plane holds one run per row then)
-		P.cap_moves = cfg.emit_runs ? maxRows * 20 + 1024 : maxRows * 2 + 1024;
-		const gal::WaveLayout lay = gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves, LW);
-		P.wave_bytes = lay.bytes;
-		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + LW * gal::kStageWords64 * 8;
+		// (node runs are five words each: the staging plane holds a run per ten rows -- six times what a path over 64-bp nodes makes; a
+		// job that needs more reports GA_CAP_TRACE and climbs on)
+		P.cap_moves = maxRows * 2 + 1024;
+		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + LW * gal::kStageWords64 * 8 + 256;
 		const uint32_t wavesPerCu = std::max<uint32_t>(1, std::min<uint32_t>(8, 163840u / ldsBytes));
+		// arena rows of a wave = the band columns of its lanes (in blocks of 8 per node), `rowsPerSlice` per lane and slice: sized for the
+		// lanes a wave will really carry
+		auto layoutFor = [&](uint32_t lanes) {
+			P.cap_rows = (uint32_t)std::min<uint64_t>(((uint64_t)P.max_slices * rowsPerSlice * lanes + 64 + 7u) & ~7ull, 0x7ffffff0ull);
+			return gal::wave_layout<N>(P.cap_cols, P.cap_rows, P.max_slices, P.cap_moves, LW);
+		};
+		gal::WaveLayout lay = layoutFor(LW);
 		const uint64_t fit = scratchBudget() / std::max<uint64_t>(lay.bytes, 1);
-		const uint64_t slotsHere = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g->cus * wavesPerCu, fit));
+		const uint64_t slotsHere = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g->cus * wavesPerCu, std::max<uint64_t>(fit, 64)));
 		// a batch that does not fill every wave slot with LW jobs is spread over all of them: a wave's steps cost the same with
 		// fewer lanes, and fewer lanes wait for each other less
 		uint32_t lanesPer = LW;
 		if (list.size() < slotsHere * LW)
 			lanesPer = (uint32_t)std::min<uint64_t>(LW, std::max<uint64_t>(8, (list.size() + slotsHere - 1) / slotsHere));
 		P.lanes_per_wave = lanesPer;
+		lay = layoutFor(lanesPer);
+		P.wave_bytes = lay.bytes;
 		const uint64_t groups = (list.size() + lanesPer - 1) / lanesPer;
 		const uint32_t waves = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(slotsHere, groups));
 		bool fromPool = false;
@@ -520,11 +529,12 @@ struct DevBatch : GaBackendBatch
 				// later sizes are only worth a launch of their own for enough jobs to fill waves; stragglers take the wave-per-read ladder
 				if (!first && list.size() < 512) break;
 				// (10 / 24 / 56 band nodes per lane = 4 / 2 / 1 waves per CU next to the 12.8 KB block image)
-				if (n == 0) rc = lanesPass<10, 64>(list, 400, first);
+				// (rows per lane and slice: the band's columns rounded up to blocks of 8 per node, with room for the widest slices)
+				if (n == 0) rc = lanesPass<10, 64>(list, 288, first);
 				// (the wider tables trade lanes for LDS per lane: 32 and 16 lanes per wave keep four waves on every CU -- the same number of
 				// reads in flight as 64-lane waves that leave three SIMDs of four idle, in four times as many instruction streams)
-				else if (n == 1) rc = lanesPass<24, 32>(list, 1024, first);
-				else rc = lanesPass<56, 16>(list, 2560, first);
+				else if (n == 1) rc = lanesPass<24, 32>(list, 480, first);
+				else rc = lanesPass<56, 16>(list, 768, first);
 				first = false;
 				std::vector<uint32_t> again;
 				for (uint32_t i : list) if (widerLanes(outs[i].status)) again.push_back(i);
@@ -572,7 +582,9 @@ struct DevBatch : GaBackendBatch
 		o = outs;
 		for (size_t i = 0; i < o.size(); i++) o[i].reserved2 = passOf[i];      // 0 = finished by the first pass
 		uint64_t top = 0;
-		HIP_OK(hipMemcpy(&top, L.trace_top, 8, hipMemcpyDeviceToHost));
+		// (on the batch's own stream: the null stream would make this wait for whatever kernel another batch is running)
+		HIP_OK(hipMemcpyAsync(&top, L.trace_top, 8, hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipStreamSynchronize(stream));
 		top = std::min<uint64_t>(top, L.trace_pool_cap);
 		hostTraces = g->takeHost(top + 64);
 		hostFromPool = hostTraces != nullptr;
@@ -582,7 +594,11 @@ struct DevBatch : GaBackendBatch
 			if (hostPrivateBytes < top + 64) { hostPrivate.reset(new uint8_t[top + 64]); hostPrivateBytes = top + 64; }
 			hostTraces = hostPrivate.get();
 		}
-		if (top) HIP_OK(hipMemcpy(hostTraces, L.traces, top, hipMemcpyDeviceToHost));
+		if (top)
+		{
+			HIP_OK(hipMemcpyAsync(hostTraces, L.traces, top, hipMemcpyDeviceToHost, stream));
+			HIP_OK(hipStreamSynchronize(stream));
+		}
 		*traces = hostTraces;
 		*nBytes = top;
 		return 0;

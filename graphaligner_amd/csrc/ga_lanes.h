@@ -70,7 +70,7 @@ struct GaLanesLaunch
 	uint64_t* trace_top;
 	uint64_t trace_pool_cap;
 	uint32_t cap_cols;             // columns per slice (end planes)
-	uint32_t cap_rows;             // arena rows per wave (sum over slices of the widest lane's band)
+	uint32_t cap_rows;             // arena rows per wave: the columns of all its lanes' bands over all slices (blocks of 8 per lane and node)
 	uint32_t max_slices;
 	uint32_t cap_moves;            // traceback moves per lane (staging)
 	int32_t initial_bw, ramp_bw;
@@ -97,15 +97,17 @@ WaveLayout wave_layout(uint32_t capCols, uint32_t capRows, uint32_t maxSlices, u
 	l.hdr = at; at = up(at + row * kHdrWords * (maxSlices + 1));
 	l.snodes = at; at = up(at + row * 2 * N * (maxSlices + 2));
 	l.moves = at; at = up(at + row * ((capMoves + 3) / 4 + 16));
-	l.arena = at; at = up(at + (uint64_t)kRecBytes * ls * (capRows + 16));
+	l.arena = at; at = up(at + (uint64_t)kRecBytes * (capRows + 16) + 64ull * 8 * kRecBytes);     // (+ the spare block image behind the rows)
 	l.bytes = at;
 	return l;
 }
 
-// where the record of (arena row, lane) lives: blocks of R consecutive rows of one lane are contiguous
+// where the record of arena row `row` lives.  Rows are handed out to lanes in blocks of R when a node is started (fill_slice), so a
+// node's columns are consecutive rows of one lane and a row belongs to exactly one lane.
 template <int R> GAL_FN uint64_t rec_off(uint32_t row, int lane, uint32_t ls)
 {
-	return ((uint64_t)(row / R) * ls + (uint32_t)lane) * (R * kRecBytes) + (uint64_t)(row % R) * kRecBytes;
+	(void)lane; (void)ls;
+	return (uint64_t)row * kRecBytes;
 }
 
 // ---- per-lane LDS tables: word i of lane l sits at lds[i * LW + l] ------------------------------------------------
@@ -163,6 +165,7 @@ struct LaneMem
 	uint32_t* moves;
 	uint8_t* arena;
 	uint64_t* stage;              // device: the wave's LDS image of the open block of 8 arena rows
+	uint32_t* laneBlocks;         // device: LDS, per lane (first arena block of the node in hand) << 13 | its number of blocks
 	uint32_t usedChunks;          // device: 16-byte chunks of a block image that belong to lanes with a job (12 per lane)
 	int lane;
 	int tid;                      // device: the thread's index in the wave (= lane, except in the variants where only the first `ls` lanes carry jobs
@@ -670,14 +673,13 @@ template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c
 #ifndef GA_EMULATE
 // the wave's 8 x 64 records of arena block `block` leave as twelve coalesced 1 KB stores: 16-byte chunk q of the 12 KB block
 // belongs to lane q / 12 (rec_off<8>: lane-major inside a block)
-template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t block, uint32_t spareBlock)
+template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t chunk, uint32_t spareRow)
 {
 	__builtin_amdgcn_wave_barrier();
-	uint8_t* dst = m.arena + (uint64_t)block * (m.ls * 8 * kRecBytes);
-	// the part of lanes that carry no job (a batch spread over more waves than it fills) goes to a spare block behind the arena's
-	// rows instead: the same few lines over and over, which the L2 absorbs -- the stores stay unconditional, HBM sees the used part
-	uint8_t* spare = m.arena + (uint64_t)spareBlock * (m.ls * 8 * kRecBytes);
-	// (a kernel whose waves carry LW < 64 jobs stages, and writes back, only those lanes' part of the block)
+	// chunk `chunk` of the nodes in hand: lane ln's 8 records (192 B) go to ITS block first + chunk when its node has that many chunks;
+	// the image of a lane whose node is shorter (or that has no job) goes to a spare block behind the arena's rows instead -- the same
+	// few lines over and over, which the L2 absorbs: the stores stay unconditional, HBM sees the live blocks only
+	uint8_t* spare = m.arena + (uint64_t)spareRow * kRecBytes;
 #pragma unroll
 	for (int j = 0; j < 12 * LW / 64; j++)
 	{
@@ -685,10 +687,20 @@ template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t block, uint
 		const uint32_t ln = q / 12u, part = q % 12u;
 		const uint64_t* sp = m.stage + ln * 25 + part * 2;
 		const uint64_t a = sp[0], b = sp[1];
-		uint64_t* d = (uint64_t*)((q < m.usedChunks ? dst : spare) + (uint64_t)q * 16);
+		const uint32_t pk = m.laneBlocks[ln];
+		const bool live = chunk < (pk & 0x1fffu);
+		uint64_t* d = (uint64_t*)(live ? m.arena + ((uint64_t)(pk >> 13) + chunk) * (8 * kRecBytes) + part * 16 : spare + (uint64_t)q * 16);
 		d[0] = a; d[1] = b;
 	}
 	__builtin_amdgcn_wave_barrier();
+}
+// blocks for the nodes the lanes start together: lane's first block = top + (blocks of the lanes before it); returns the wave's total
+GAL_FN uint32_t wave_alloc(uint32_t mine, uint32_t top, uint32_t& first)
+{
+	uint32_t incl = mine;
+	for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64); if ((int)(threadIdx.x & 63) >= off) incl += o; }
+	first = top + incl - mine;
+	return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 #endif
 
@@ -728,7 +740,7 @@ GAL_FN uint32_t wave_max(uint32_t v) { return v; }
 #endif
 
 template <int N, int U, int LW = 64>
-GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uint32_t slice, bool active, uint32_t& rowTop, uint32_t capRows, uint32_t capCols)
+GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uint32_t slice, bool active, uint32_t& blockTop, uint32_t capRows, uint32_t capCols)
 {
 	typedef Lay<N> LY;
 	const Lds& l = m.lds;
@@ -741,7 +753,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 	int sliceMin = INF, minSlot = -1;
 	uint32_t minOffset = 0;
 	int status = GA_OK;
-	uint32_t tick = rowTop;                       // arena row of the wave's next step
+	uint32_t tick = blockTop;                     // the arena's next free block of U rows (device: of the wave; emulation: of the lane's own arena)
 	// requested ahead for the node at `ord`
 	uint32_t nFirstLo = 0, nFirstHi = 0, nPend0 = 0;
 	auto request = [&](int o) {
@@ -797,9 +809,23 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 		const bool aboveAlways = j0 && inPrev;                                   // "previousEq" (:1503): raw char ==, not characterMatch
 		const uint32_t* pend = m.endPrev + (uint64_t)pbase * m.ls;
 		static_assert(U == 8, "a chunk is one block of 8 arena rows");
-		const uint32_t nChunks = (wave_max(len) + U - 1) / U;                    // the wave's nodes go in chunks of U columns = blocks of U arena rows
-		if (tick + nChunks * U + U > capRows) { if (act) status = GA_CAP_ARENA; ord = -1; break; }
-		const uint32_t t0 = tick;                                                // arena row of the node's column 0 (a multiple of U)
+		const uint32_t nChunks = (wave_max(len) + U - 1) / U;                    // the wave's nodes go in chunks of U columns
+		// every lane takes the blocks of U arena rows its own node needs (lanes whose node is shorter, or that have none, take fewer):
+		// a node's columns are consecutive rows, and no row is spent on a lane that has nothing to put there
+		const uint32_t myBlocks = act ? (len + U - 1) / U : 0u;
+		uint32_t firstBlock = tick;
+#ifdef GA_EMULATE
+		const uint32_t allBlocks = myBlocks;
+#else
+		const uint32_t allBlocks = wave_alloc(myBlocks, tick, firstBlock);
+#endif
+		if ((uint64_t)(tick + allBlocks + 1) * U > capRows) { if (act) status = GA_CAP_ARENA; ord = -1; break; }
+		const uint32_t t0 = firstBlock * U;                                      // arena row of the node's column 0
+#ifndef GA_EMULATE
+		__builtin_amdgcn_wave_barrier();
+		if (m.tid < LW) m.laneBlocks[m.lane] = (firstBlock << 13) | myBlocks;
+		__builtin_amdgcn_wave_barrier();
+#endif
 		// operands of the first chunk (columns 0 .. U-1; column 0 itself comes from the node start below).  Requests are unconditional
 		// (lanes without a previous column read a valid dummy row) so that the compiler can count them.
 		const uint32_t* pendSafe = (act && inPrev) ? pend : m.endPrev;
@@ -938,13 +964,13 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 				emit(on, w, i);
 			}
 #ifndef GA_EMULATE
-			stage_flush<LW>(m, (t0 >> 3) + j, capRows >> 3);                                       // the chunk's block of U rows is complete
+			stage_flush<LW>(m, j, capRows + 8);                                                   // the chunk's blocks of U rows are complete
 #endif
 #pragma unroll
 			for (int i = 0; i < U; i++) pe[i] = pe2[i];
 			bw = bw2;
 		}
-		tick = t0 + nChunks * U;
+		tick += allBlocks;
 		if (act)
 		{
 			if (c.before != zero) { status = GA_ASSERTION; ord = -1; }            // assert(newEnd.scoreBeforeStart == oldEnd.scoreBeforeStart) (:2385)
@@ -957,7 +983,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 			}
 		}
 	}
-	rowTop = tick;
+	blockTop = tick;
 	if (active)
 	{
 		st.sliceMin = sliceMin; st.minSlot = minSlot; st.minOffset = minOffset;

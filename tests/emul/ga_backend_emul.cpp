@@ -76,7 +76,9 @@ struct EmulBatch : GaBackendBatch
 		L.initial_bw = cfg.initial_bw; L.ramp_bw = cfg.ramp_bw;
 		L.emit_runs = cfg.emit_runs;
 		const WaveLayout lay = wave_layout<N>(capCols, capRows, cfg.max_slices, capMoves);
-		std::vector<uint8_t> scratch(lay.bytes + 256);
+		// (on the device the lanes of a wave take their arena blocks from one pool; run one after the other, every lane gets an arena of its own)
+		const uint64_t laneArena = lay.bytes - lay.arena;
+		std::vector<uint8_t> scratch(lay.arena + 64 * laneArena + 256);
 		std::vector<uint32_t> lds((size_t)(Lay<N>::WORDS + kStageWordsLane) * 64);     // tables + the words of the staging image behind them
 		std::vector<LaneMem> mem(64);
 		std::vector<LaneState> st(64);
@@ -90,7 +92,7 @@ struct EmulBatch : GaBackendBatch
 			m.hdr = (uint32_t*)(scratch.data() + lay.hdr) + lane;
 			m.snodes = (uint32_t*)(scratch.data() + lay.snodes) + lane;
 			m.moves = (uint32_t*)(scratch.data() + lay.moves) + lane;
-			m.arena = scratch.data() + lay.arena;
+			m.arena = scratch.data() + lay.arena + (uint64_t)lane * laneArena;
 			m.stage = nullptr;
 			const bool has = lane < (int)group.size();
 			lane_begin<N>(L, m, st[lane], has ? group[lane] : 0, has);
