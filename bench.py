@@ -160,18 +160,34 @@ def main():
             return
         with ThreadPoolExecutor(max_workers=1) as pool:
             pending = None
+            timeline = [] if (record and os.environ.get("GA_BENCH_TIMELINE")) else None
+            t_base = time.perf_counter()
+
+            def collect_of(b, k):
+                ta = time.perf_counter()
+                r = b.collect(True)
+                if timeline is not None:
+                    timeline.append(("collect", k, ta - t_base, time.perf_counter() - t_base))
+                return r
+
             for k in range(n):
                 b = batch if (twin is None or k % 2 == 0) else twin
+                ta = time.perf_counter()
                 b.run()
+                if timeline is not None:
+                    timeline.append(("run", k, ta - t_base, time.perf_counter() - t_base))
                 if record:
                     sk = b.stats()
                     kernel_ms.append(sk["kernel_ms"])
                     main_kernel_ms.append(sk["main_kernel_ms"])
                 if pending is not None:
                     pending.result()
-                pending = None if args.kernel_only else pool.submit(b.collect, True)
+                pending = None if args.kernel_only else pool.submit(collect_of, b, k)
             if pending is not None:
                 pending.result()
+            if timeline:
+                for what, k, ta, tb in sorted(timeline, key=lambda e: e[2]):
+                    print("   %-8s step %d  %7.1f .. %7.1f ms" % (what, k, ta * 1e3, tb * 1e3), file=sys.stderr)
 
     run_steps(args.warmup, False)
     barrier()

@@ -165,7 +165,44 @@ struct DevGraph : GaBackendGraph
 	uint8_t* pool = nullptr;
 	size_t poolBytes = 0;
 	bool poolBusy = false;
-	~DevGraph() override { hipSetDevice(device); for (void* p : allocs) hipFree(p); if (pool) hipFree(pool); if (hostPool) hipHostFree(hostPool); }
+	~DevGraph() override
+	{
+		hipSetDevice(device);
+		for (void* p : allocs) hipFree(p);
+		for (auto& b : idleBlocks) hipFree(b.second);
+		if (pool) hipFree(pool);
+		if (hostPool) hipHostFree(hostPool);
+	}
+	// device buffers of the batches (match words, jobs, outputs, trace pool): handed back here instead of hipFree'd, because hipFree
+	// waits for the whole device -- i.e. for the kernels of whatever batch is running -- and the stages of consecutive batches are
+	// meant to overlap (sharding.run_overlapped).  A later batch of similar size takes them again.
+	std::mutex blockLock;
+	std::vector<std::pair<size_t, void*>> idleBlocks;
+	void* takeBlock(size_t bytes)
+	{
+		{
+			std::lock_guard<std::mutex> lock(blockLock);
+			size_t best = idleBlocks.size();
+			for (size_t i = 0; i < idleBlocks.size(); i++)
+				if (idleBlocks[i].first >= bytes && idleBlocks[i].first <= bytes + bytes / 2 + 4096 && (best == idleBlocks.size() || idleBlocks[i].first < idleBlocks[best].first)) best = i;
+			if (best != idleBlocks.size())
+			{
+				void* p = idleBlocks[best].second;
+				idleBlocks.erase(idleBlocks.begin() + (long)best);
+				return p;
+			}
+		}
+		void* p = nullptr;
+		if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+		return p;
+	}
+	void giveBlock(void* p, size_t bytes)
+	{
+		std::lock_guard<std::mutex> lock(blockLock);
+		// (bounded: beyond a few dozen idle blocks the oldest go back to the device)
+		if (idleBlocks.size() >= 48) { hipFree(idleBlocks.front().second); idleBlocks.erase(idleBlocks.begin()); }
+		idleBlocks.emplace_back(bytes, p);
+	}
 	// (one graph can serve batches run from several host threads: the pool changes hands under a lock)
 	std::mutex poolLock;
 	uint8_t* takePool(size_t bytes)
@@ -237,7 +274,7 @@ struct DevBatch : GaBackendBatch
 	Knobs knobs;
 	hipStream_t stream = nullptr;
 	hipEvent_t evA = nullptr, evB = nullptr;
-	std::vector<void*> allocs;
+	std::vector<std::pair<size_t, void*>> allocs;     // (bytes, block) from the graph's block list
 	std::vector<GaJob> jobs;
 	GaRunConfig cfg;
 	GaLaunch L;                 // what every pass shares (graph, reads, jobs, outputs, trace pool); scratch geometry is set per pass
@@ -257,7 +294,7 @@ struct DevBatch : GaBackendBatch
 	{
 		hipSetDevice(g->device);
 		if (hostFromPool) g->giveHost();
-		for (void* p : allocs) hipFree(p);
+		for (auto& a : allocs) g->giveBlock(a.second, a.first);
 		if (privateScratch) hipFree(privateScratch);
 		if (evA) hipEventDestroy(evA);
 		if (evB) hipEventDestroy(evB);
@@ -265,9 +302,10 @@ struct DevBatch : GaBackendBatch
 	}
 	template <typename T> int alloc(T** out, size_t count)
 	{
-		void* p = nullptr;
-		HIP_OK(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
-		allocs.push_back(p);
+		const size_t bytes = (std::max<size_t>(count * sizeof(T), 16) + 255) & ~(size_t)255;
+		void* p = g->takeBlock(bytes);
+		if (!p) { fprintf(stderr, "graphaligner_amd: no device memory for %zu bytes\n", bytes); return GA_E_DEVICE; }
+		allocs.emplace_back(bytes, p);
 		*out = (T*)p;
 		return 0;
 	}

@@ -3,6 +3,7 @@
 // extension jobs (GraphAligner.h:2969-3024), and turning the device's raw traces back into
 // AlignmentResults (GraphAligner.h:408-491, 594-847, 3026-3098).  No alignment arithmetic
 // happens here; the extension program runs behind ga_backend.h on the GPU.
+#include <sched.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -259,6 +260,37 @@ struct SeedPlan
 	uint64_t pos = 0;
 };
 
+// threads this process can really run at once: the affinity mask, capped by a cgroup CPU quota.  More threads than that are worse than
+// useless under a quota: a burst of 64 threads on 16 cores' worth of quota spends the period's budget in a quarter of the period and the
+// whole process -- the thread that waits for the GPU included -- is throttled for the rest of it.
+static size_t usableCores()
+{
+	static const size_t cached = []() -> size_t {
+		size_t n = std::thread::hardware_concurrency();
+#ifdef __linux__
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min<size_t>(n ? n : (size_t)c, (size_t)c); }
+		if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+		{
+			char quota[32]; long long period = 0;
+			if (fscanf(f, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+				n = std::min<size_t>(n, (size_t)std::max<long long>(1, (atoll(quota) + period / 2) / period));
+			fclose(f);
+		}
+		else if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))
+		{
+			long long quota = -1, period = 0;
+			if (fscanf(q, "%lld", &quota) != 1) quota = -1;
+			fclose(q);
+			if (FILE* pf = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(pf, "%lld", &period) != 1) period = 0; fclose(pf); }
+			if (quota > 0 && period > 0) n = std::min<size_t>(n, (size_t)std::max<long long>(1, (quota + period / 2) / period));
+		}
+#endif
+		return std::max<size_t>(1, n);
+	}();
+	return cached;
+}
+
 struct ReadPlan { size_t firstSeed = 0, nSeeds = 0; };
 
 // (a mapping's edit sequence is a piece of the read: kept as a span of it, copied once into the results)
@@ -272,7 +304,8 @@ struct ga_batch
 	const ga_graph* g = nullptr;
 	std::vector<std::string> names;
 	std::vector<ReadSeq> seqs;            // into seqBuf
-	char* seqBuf = nullptr;
+	char* seqBuf = nullptr;               // the batch's own copy of the reads, one buffer; shared with the results collected from the batch:
+	std::shared_ptr<char> seqKeep;        // an Edit's sequence is a piece of the read (GraphAligner.h:829, 845), so results point into it
 	size_t seqBufBytes = 0;
 	std::vector<ReadPlan> reads;
 	std::vector<SeedPlan> seeds;
@@ -288,14 +321,14 @@ struct ga_batch
 	GaBackendBatch* dev = nullptr;
 	bool ran = false;
 	uint64_t columnUpdates = 0, slicesRun = 0, rowsTotal = 0;
-	~ga_batch() { delete dev; free(seqBuf); }
+	~ga_batch() { delete dev; }
 };
 
 // run `fn(fill, read sequence)` for every job's rows on the host threads
 template <typename F> static void forEachFill(ga_batch* b, F fn)
 {
 	const auto& fills = b->fills;
-	size_t nThreads = std::thread::hardware_concurrency();
+	size_t nThreads = usableCores();
 	if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
 	nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), fills.size() / 64 + 1));
 	std::vector<std::thread> pool;
@@ -385,7 +418,8 @@ struct ResultsOwner
 	std::vector<char> edits;
 	std::vector<ga_trace_item_t> trace;
 	// the arrays of a whole batch (hundreds of MB, not cleared first): from the process-wide pool below, back to it with the results
-	PooledBuffer allReads, allMappings, allEdits, allTrace;
+	PooledBuffer allReads, allMappings, allTrace;
+	std::shared_ptr<char> seqKeep;        // edit_bytes of a batch's results = the batch's copy of the reads, kept alive here
 };
 
 int mapDeviceStatus(int s)
@@ -732,10 +766,11 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		void* mem = nullptr;
 		if (posix_memalign(&mem, 2u << 20, (b->seqBufBytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1)) != 0) { delete b; return GA_E_INVALID; }
 		b->seqBuf = (char*)mem;
+		b->seqKeep = std::shared_ptr<char>((char*)mem, [](char* p) { free(p); });
 #ifdef MADV_HUGEPAGE
 		madvise(mem, (b->seqBufBytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1), MADV_HUGEPAGE);
 #endif
-		size_t nThreads = std::thread::hardware_concurrency();
+		size_t nThreads = usableCores();
 		if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
 		nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 16), nReads / 256 + 1));
 		std::vector<std::thread> pool;
@@ -954,12 +989,14 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 			for (int64_t job : {b->seeds[k].bwJob, b->seeds[k].fwJob})
 				if (job >= 0 && outs[job].status == GA_OK) { runs += (uint64_t)outs[job].n_node_steps + 1; items += (uint64_t)outs[job].trace_len + 2; }
 		mapAt[ri + 1] = mapAt[ri] + runs;
-		editAt[ri + 1] = editAt[ri] + b->seqs[ri].size() + 8;
+		editAt[ri + 1] = editAt[ri] + b->seqs[ri].size();
 		traceAt[ri + 1] = traceAt[ri] + (wantTraceAll ? items : 0);
 	}
 	ga_read_result_t* const allReads = (ga_read_result_t*)R->allReads.get((nReadsAll + 1) * sizeof(ga_read_result_t));
 	ga_mapping_t* const allMappings = (ga_mapping_t*)R->allMappings.get((mapAt[nReadsAll] + 1) * sizeof(ga_mapping_t));
-	char* const allEdits = (char*)R->allEdits.get(editAt[nReadsAll] + 1);
+	// (no copy of the edit sequences: they are pieces of the reads, and the results share the batch's read buffer)
+	const char* const allEdits = b->seqBuf;
+	R->seqKeep = b->seqKeep;
 	ga_trace_item_t* const allTrace = (ga_trace_item_t*)R->allTrace.get((traceAt[nReadsAll] + 1) * sizeof(ga_trace_item_t));
 	if (!allReads || !allMappings || !allEdits || !allTrace) { delete R; b->dev->fetchDone(); return GA_E_INVALID; }
 	std::atomic<uint64_t> columnUpdatesAll{0}, forwardOnlyReads{0};
@@ -1062,9 +1099,8 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 			m.from_length = (int64_t)r.lastOffset - (int64_t)r.firstOffset + (k + 1 < nRuns ? 1 : 0);        // no +1 on the last mapping (:843)
 			m.to_length = (int64_t)(r.lastRow - beforeRow);
 			const SeqSpan piece = spanOf(seq, r.firstRow, r.lastRow - beforeRow);
-			m.edit_seq_off = editTop;
+			m.edit_seq_off = (uint64_t)(seq.data() - allEdits) + piece.pos;
 			if (piece.len > editAt[ri + 1] - editTop) { overflow.store(1); rr.status = GA_E_DEVICE; return true; }
-			memcpy(allEdits + editTop, seq.data() + piece.pos, piece.len);
 			editTop += piece.len;
 			allMappings[mapAt[ri] + k] = m;
 			beforeRow = r.lastRow;
@@ -1192,8 +1228,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		for (size_t i = 0; i < merged.maps.size(); i++)
 		{
 			ga_mapping_t m = merged.maps[i];
-			m.edit_seq_off = editTop;
-			memcpy(allEdits + editTop, seq.data() + merged.seqs[i].pos, merged.seqs[i].len);
+			m.edit_seq_off = (uint64_t)(seq.data() - allEdits) + merged.seqs[i].pos;
 			editTop += merged.seqs[i].len;
 			allMappings[mapAt[ri] + i] = m;
 		}
@@ -1207,7 +1242,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	columnUpdatesAll += columnUpdates;
 	};
 	// reads are independent: assembled on several host threads
-	size_t nThreads = std::thread::hardware_concurrency();
+	size_t nThreads = usableCores();
 	if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
 	nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 64), nReadsAll / 64 + 1));
 	{
@@ -1232,7 +1267,7 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 	if (overflow.load()) { delete R; return GA_E_DEVICE; }
 	R->pub.n_reads = nReadsAll; R->pub.reads = allReads;
 	R->pub.n_mappings = mapAt[nReadsAll]; R->pub.mappings = allMappings;
-	R->pub.n_edit_bytes = editAt[nReadsAll]; R->pub.edit_bytes = allEdits;
+	R->pub.n_edit_bytes = b->seqBufBytes; R->pub.edit_bytes = allEdits;
 	R->pub.n_trace = traceAt[nReadsAll]; R->pub.trace = allTrace;
 	*out = &R->pub;
 	if (getenv("GA_DEBUG_COLLECT"))
@@ -1258,7 +1293,8 @@ int ga_results_unsplit(const ga_graph_t* g, const ga_results_t* in, ga_results_t
 {
 	if (!g || !in || !out) return GA_E_INVALID;
 	ResultsOwner* R = new ResultsOwner();
-	R->edits.assign(in->edit_bytes, in->edit_bytes + in->n_edit_bytes);
+	// (every mapping's edit sequence is copied: the pieces of merged mappings are joined here, whatever lies between them in `in`)
+	R->edits.reserve(in->n_edit_bytes / 4 + 64);
 	auto piece = [&](int64_t digraphId) -> const ga_graph::Piece* {
 		auto it = g->pieces.find(digraphId / 2);
 		return it == g->pieces.end() ? nullptr : &it->second;
@@ -1271,6 +1307,8 @@ int ga_results_unsplit(const ga_graph_t* g, const ga_results_t* in, ga_results_t
 		for (uint64_t k = 0; k < rr.n_mappings; k++)
 		{
 			ga_mapping_t m = in->mappings[rr.first_mapping + k];
+			const char* const editFrom = in->edit_bytes + m.edit_seq_off;
+			const size_t editLen = (size_t)m.to_length;
 			const ga_graph::Piece* p = piece(m.node_id);
 			if (p)
 			{
@@ -1284,6 +1322,7 @@ int ga_results_unsplit(const ga_graph_t* g, const ga_results_t* in, ga_results_t
 					{
 						last.from_length += m.from_length;
 						last.to_length += m.to_length;
+						R->edits.insert(R->edits.end(), editFrom, editFrom + editLen);
 						prevPiece = p;
 						continue;
 					}
@@ -1293,6 +1332,8 @@ int ga_results_unsplit(const ga_graph_t* g, const ga_results_t* in, ga_results_t
 			}
 			prevPiece = p;
 			m.rank = (int32_t)(R->mappings.size() - firstMap);
+			m.edit_seq_off = R->edits.size();
+			R->edits.insert(R->edits.end(), editFrom, editFrom + editLen);
 			R->mappings.push_back(m);
 		}
 		for (uint64_t k = 0; k < rr.n_trace; k++)

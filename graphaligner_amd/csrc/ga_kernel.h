@@ -15,10 +15,14 @@
 //   * one pass: every slice's VP/VN/score words are kept in HBM (20 B per column) and the
 //     traceback reads them directly, instead of the reference's sqrt-checkpoint + recompute.
 //
-// The same source builds for gfx950 (product) and, with GA_EMULATE, for the host (tests only).
+// The same source builds for gfx950 (product, wave primitives of ga_wave.h) and for the host (tests only: tests/emul substitutes its
+// own back end for ga_wave.h through GA_WAVE_HEADER).
 #pragma once
 #include "ga_types.h"
-#include "ga_wave.h"
+#ifndef GA_WAVE_HEADER
+#define GA_WAVE_HEADER "ga_wave.h"
+#endif
+#include GA_WAVE_HEADER
 
 namespace gak {
 using namespace gaw;

@@ -198,3 +198,23 @@ def test_single_contig_gfa_needs_split_then_matches_oracle_of_cut_graph():
         assert m["mappings"][0][5] == sum(x[5] for x in r["mappings"])
         assert abs(m["mappings"][0][2] - st) <= 64
         assert (m["trace"][:, 0] == 1).all() and (np.diff(m["trace"][m["trace"][:, 4] != 5][:, 2].astype(np.int64)) >= 0).all()
+
+
+def test_c2_full_length_reads_on_the_64bp_chain():
+    """BASELINE configuration 2 at full READ length: 10 kb ONT-error reads on a chain of 64-bp nodes (a 1.2 Mbp stretch of the genome
+    bench.py uses, band 35, one seed at the first base) -- 256 reads, EVERY one compared with the oracle, with and without TraceItem
+    lists (the second is the path bench.py times: node runs straight from the traceback), under both first-pass choices"""
+    g = synth.linear_graph(1200000, node_len=64, seed=42)
+    reads, seeds = synth.simulate_reads(g, 256, 10000, sub=0.04, ins=0.04, dele=0.04, seed=43)
+    og = ob.OracleGraph(g.nodes, g.edges)
+    graph = binding.Graph(gfa=g.gfa())
+    with_items = graph.align(reads, seeds, 35, 0, flags=binding.GA_F_TRACE)
+    plain = graph.align(reads, seeds, 35, 0, flags=0)
+    n_ok = 0
+    for i, (r, s) in enumerate(zip(reads, seeds)):
+        o = og.align(r, [s], 35)
+        pc.compare_read(with_items[i], o, "C2 read %d" % i)
+        pc.compare_read(plain[i], dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "C2 read %d without trace items" % i)
+        n_ok += 0 if o["failed"] else 1
+    assert n_ok >= 250
+    _properties(with_items, reads, seeds, 250)
