@@ -265,12 +265,14 @@ def main():
     # HBM traffic per launch: PMC counters cannot be read from inside this process, so the per-column-update figure measured with
     # rocprofv3 --pmc on this kernel and this workload (tools/pmc_lanes.sh -> profiles/r2_hbm_traffic.json) is scaled to this launch
     traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
     if os.path.exists(tpath) and args.graph == "linear":
         tj = json.load(open(tpath))
         if tj.get("kernel", "").startswith(kernel_name.split("<")[0]):
             traffic = int(tj["hbm_bytes_per_column_update"] * st["column_updates"])
-            traffic_note = "scaled from profiles/r2_hbm_traffic.json (%s B per column update, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build %s)" % (tj["hbm_bytes_per_column_update"], tj.get("build", "?"))
+            traffic_note = "scaled from profiles/%s (%s B per column update, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build %s)" % (os.path.basename(tpath), tj["hbm_bytes_per_column_update"], tj.get("build", "?"))
     if args.graph == "linear":
         workload = ("E. coli-scale single-contig GFA (one %d-bp segment, seed 42, loaded cut into %d-bp pieces) + %d x %d bp simulated ONT-error reads (s,i,d=%s, seed 43), band=%d, 1 seed/read at pos 0"
                     % (args.genome, args.node_len, args.reads, args.read_len, args.errors, args.bandwidth))

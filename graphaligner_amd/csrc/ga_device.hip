@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 		LaneMem m;
 		m.lane = lane < LW ? lane : 0;      // (lanes beyond the variant's LW carry no job: they shadow lane 0's addresses and store nothing)
 		m.tid = lane;
+		m.flushPart = (uint32_t)lane % 12u; m.flushLane = (uint32_t)lane / 12u;
 		m.ls = LW;
 		m.lds.base = lds + (lane < LW ? lane : 0);
 		m.lds.lw = LW;

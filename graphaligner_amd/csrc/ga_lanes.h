@@ -14,7 +14,8 @@
 //
 // Memory, all sized per wave:
 //   LDS      per-lane band tables, [word][lane] interleaved (bank = lane: never a conflict), 10 * MAXN words per lane
-//   HBM      end words of the previous / current slice  [column][lane]                       (4 B per column)
+//   HBM      end words of the previous / current slice  [column][lane]                       (4 B per column; measured against
+//            [lane][column]: the lane-major form is 12 % slower, profiles/r3_ab_arena.txt)
 //            slice records: VP, VN, scoreBeforeStart, end word = 24 B per column, in blocks of R columns per lane
 //            per-slice headers and band node lists for the traceback, [slice][k][lane]
 //            traceback moves, 4 per word, [k][lane]
@@ -154,7 +155,7 @@ struct Lds
 	GAL_FN void wrb(int word, int k, uint32_t v) const { ((uint8_t*)(base + (word + (k >> 2)) * lw))[k & 3] = (uint8_t)v; }
 };
 
-// a lane's view of its wave's HBM scratch: plane[k * 64] is entry k of this lane
+// a lane's view of its wave's HBM scratch: plane[k * ls] is entry k of this lane
 struct LaneMem
 {
 	Lds lds;
@@ -168,6 +169,7 @@ struct LaneMem
 	uint32_t* laneBlocks;         // device: LDS, per lane (first arena block of the node in hand) << 13 | its number of blocks
 	uint32_t usedChunks;          // device: 16-byte chunks of a block image that belong to lanes with a job (12 per lane)
 	int lane;
+	uint32_t flushPart, flushLane; // device: this thread's place in the block flush (tid % 12, tid / 12)
 	int tid;                      // device: the thread's index in the wave (= lane, except in the variants where only the first `ls` lanes carry jobs
 	                              // and the others shadow lane 0: every thread still takes part in the block flush)
 	uint32_t ls;                  // lane stride of the planes and of the arena's blocks (a constant of the kernel variant: 64, 32 or 16)
@@ -673,23 +675,25 @@ template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c
 #ifndef GA_EMULATE
 // the wave's 8 x 64 records of arena block `block` leave as twelve coalesced 1 KB stores: 16-byte chunk q of the 12 KB block
 // belongs to lane q / 12 (rec_off<8>: lane-major inside a block)
-template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t chunk, uint32_t spareRow)
+template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t chunk)
 {
 	__builtin_amdgcn_wave_barrier();
-	// chunk `chunk` of the nodes in hand: lane ln's 8 records (192 B) go to ITS block first + chunk when its node has that many chunks;
-	// the image of a lane whose node is shorter (or that has no job) goes to a spare block behind the arena's rows instead -- the same
-	// few lines over and over, which the L2 absorbs: the stores stay unconditional, HBM sees the live blocks only
-	uint8_t* spare = m.arena + (uint64_t)spareRow * kRecBytes;
+	// chunk `chunk` of the nodes in hand: lane ln's 8 records (192 B) go to ITS block first + chunk.  Twelve threads write one lane's
+	// block (16 B each); thread t serves lanes t / 12, t / 12 + 5, ... -- five lanes per store instruction, every LDS address a constant of
+	// the thread plus an immediate.  A lane whose node has fewer chunks is not active any more and its image still holds its LAST chunk:
+	// it is written to that last block again (the same bytes); a lane without a node this round points at the spare block (laneBlocks).
+	const uint32_t part = m.flushPart, g = m.flushLane;
+	const bool worker = m.tid < 60;
 #pragma unroll
-	for (int j = 0; j < 12 * LW / 64; j++)
+	for (int j = 0; j < (LW + 4) / 5; j++)
 	{
-		const uint32_t q = (uint32_t)m.tid + 64u * (uint32_t)j;
-		const uint32_t ln = q / 12u, part = q % 12u;
+		const uint32_t ln = (worker && g + 5u * (uint32_t)j < (uint32_t)LW) ? g + 5u * (uint32_t)j : 0u;
 		const uint64_t* sp = m.stage + ln * 25 + part * 2;
 		const uint64_t a = sp[0], b = sp[1];
 		const uint32_t pk = m.laneBlocks[ln];
-		const bool live = chunk < (pk & 0x1fffu);
-		uint64_t* d = (uint64_t*)(live ? m.arena + ((uint64_t)(pk >> 13) + chunk) * (8 * kRecBytes) + part * 16 : spare + (uint64_t)q * 16);
+		const uint32_t last = (pk & 0x1fffu) - 1u;
+		const uint32_t at16 = ((pk >> 13) + (chunk < last ? chunk : last)) * 12u + part;          // in 16-byte units from the arena's start
+		uint64_t* d = (uint64_t*)(m.arena + (uint64_t)at16 * 16);
 		d[0] = a; d[1] = b;
 	}
 	__builtin_amdgcn_wave_barrier();
@@ -823,7 +827,8 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 		const uint32_t t0 = firstBlock * U;                                      // arena row of the node's column 0
 #ifndef GA_EMULATE
 		__builtin_amdgcn_wave_barrier();
-		if (m.tid < LW) m.laneBlocks[m.lane] = (firstBlock << 13) | myBlocks;
+		// (a lane without a node this round points at the spare block behind the arena's rows)
+		if (m.tid < LW) m.laneBlocks[m.lane] = myBlocks ? ((firstBlock << 13) | myBlocks) : ((((capRows >> 3) + 1u) << 13) | 1u);
 		__builtin_amdgcn_wave_barrier();
 #endif
 		// operands of the first chunk (columns 0 .. U-1; column 0 itself comes from the node start below).  Requests are unconditional
@@ -964,7 +969,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 				emit(on, w, i);
 			}
 #ifndef GA_EMULATE
-			stage_flush<LW>(m, j, capRows + 8);                                                   // the chunk's blocks of U rows are complete
+			stage_flush<LW>(m, j);                                                                // the chunk's blocks of U rows are complete
 #endif
 #pragma unroll
 			for (int i = 0; i < U; i++) pe[i] = pe2[i];

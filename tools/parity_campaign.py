@@ -27,7 +27,7 @@ def main(argv=None, quiet=False):
     import parity_common as pc
     lib = pc.emul_lib_path() if args.emul else None
     rng = np.random.default_rng(args.seed)
-    stats = dict(reads=0, compared=0, mismatches=0, cyclic_trials=0, ramp_trials=0, dev_status={}, first_mismatches=[])
+    stats = dict(reads=0, compared=0, mismatches=0, cyclic_trials=0, ramp_trials=0, fan_trials=0, sparse_slices=0, override_traces=0, dev_status={}, first_mismatches=[])
     t0 = time.time()
     for trial in range(args.trials):
         nl = int(rng.choice([3, 8, 16, 32, 64, 100]))
@@ -43,8 +43,31 @@ def main(argv=None, quiet=False):
         if trial % 4 == 2:               # -B: narrow band first, ramp width on demand (damaged reads make the HMM flip)
             bw = int(rng.choice([3, 5, 10, 15]))
             ramp = bw + int(rng.choice([15, 30, 60]))
+        fan = trial % 7 == 5             # a stem ending in many long branches: bands of >= 200 000 cells (sparse method, backtrace override)
         try:
-            if cyclic:
+            if fan:
+                branches = int(rng.choice([5, 8, 12, 40]))
+                blen = int(rng.choice([60000, 30000, 20000, 6000])) if branches < 40 else 6000
+                if branches * blen < 230000:
+                    blen = 230000 // branches + 1000
+                fg = synth.FanGraph(head_len=int(rng.choice([100, 200, 400])), stem_len=int(rng.choice([300, 600, 1200])), n_branches=branches, branch_len=blen,
+                                    shared=int(rng.choice([0, 100, 300, 600])), seed=trial)
+                g = fg
+                reads, seeds = [], []
+                for k in range(min(args.reads, 8)):
+                    if k % 3 != 2:
+                        r, sd = fg.read_through(int(rng.integers(0, branches)), 0, int(rng.choice([1200, 2000, 3000])), rng, sub=err, ins=err, dele=err)
+                    else:
+                        b2 = int(rng.integers(0, branches))
+                        depth = int(rng.integers(300, 1500))
+                        path = np.concatenate([fg.head, fg.stem, fg.branches[b2][:depth + 800]])
+                        cut = len(fg.head) + len(fg.stem) + depth
+                        pre = synth.add_errors(path[:cut], err, err, err, rng).tobytes().decode()
+                        r, sd = pre + synth.add_errors(path[cut:], err, err, err, rng).tobytes().decode(), (3 + b2, len(pre), False)
+                    reads.append(r); seeds.append(sd)
+                if ramp == 0 and trial % 2 == 1:
+                    ramp = bw + 25
+            elif cyclic:
                 g = synth.cyclic_graph(int(rng.choice([4000, 9000])), node_len=max(nl, 4), seed=trial, back_edges=int(rng.integers(2, 12)), self_loops=int(rng.integers(0, 4)),
                                        max_span=int(rng.integers(1, 9)), snp_every=snp if snp else 60)
                 reads, seeds = synth.walk_reads(g, args.reads, min(L, 3000), sub=err, ins=err, dele=err, seed=trial, mid_seed=mid, first_nodes=max(1, len(g.nodes) // 3))
@@ -53,7 +76,8 @@ def main(argv=None, quiet=False):
                 reads, seeds = synth.simulate_reads(g, args.reads, L, sub=err, ins=err, dele=err, seed=trial, mid_seed=mid)
         except RuntimeError:
             continue
-        stats["cyclic_trials"] += int(cyclic)
+        stats["fan_trials"] += int(fan)
+        stats["cyclic_trials"] += int(cyclic and not fan)
         stats["ramp_trials"] += int(ramp > 0)
         if ramp:
             import parity_cases
@@ -71,6 +95,8 @@ def main(argv=None, quiet=False):
             oras = [dict(o, trace=np.zeros((0, 7), dtype=np.int64)) for o in oras]
         for i, (d, o) in enumerate(zip(devs, oras)):
             stats["reads"] += 1
+            stats["sparse_slices"] += o.get("sparse_slices", 0)
+            stats["override_traces"] += o.get("override_traces", 0)
             stats["dev_status"][str(d["status"])] = stats["dev_status"].get(str(d["status"]), 0) + 1
             if d["status"] in (10, 11, 12, 13, 14):
                 continue      # band beyond the widest kernel variant: reported as a capacity status, never a silently different answer

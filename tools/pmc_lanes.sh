@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 O=gpurun_out/pmc_lanes
 rm -rf $O && mkdir -p $O
 run() { name=$1; shift; pmc=$1; shift
-  rocprofv3 --pmc $pmc --output-format csv -d $O/$name -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --accuracy 0 --pipeline-chunks 0 "$@" > $O/$name.json 2> $O/$name.err; echo "$name done"; }
+  rocprofv3 --pmc $pmc --output-format csv -d $O/$name -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --check 0 --accuracy 0 --pipeline-chunks 0 --kernel-only "$@" > $O/$name.json 2> $O/$name.err; echo "$name done"; }
 run a "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "$@"
 run b "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES" "$@"
 run fetch "FETCH_SIZE" "$@"
@@ -31,7 +31,7 @@ if 'WRITE_SIZE' in out: out['hbm_write_bytes'] = out['WRITE_SIZE'] * 1024
 out['per_column_update'] = {k: round(v / cols, 3) for k, v in out.items() if k.startswith('SQ_') or k.startswith('TCC')}
 json.dump(out, open('$O/summary.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
-# the HBM traffic per column update that bench.py scales to its own launch (-> profiles/r2_hbm_traffic.json)
+# the HBM traffic per column update that bench.py scales to its own launch (-> profiles/r3_hbm_traffic.json)
 if 'FETCH_SIZE' in out and 'WRITE_SIZE' in out:
     rd, wr = out['FETCH_SIZE'] * 1024, out['WRITE_SIZE'] * 1024
     t = {
@@ -46,7 +46,7 @@ if 'FETCH_SIZE' in out and 'WRITE_SIZE' in out:
      "hbm_bytes_per_column_update_uncorrected": (rd + wr) / cols,
      "algorithmic_bytes_per_column_update": 28.0,
      "kernel_ms_under_counters": b['roofline']['kernel_ms'],
-     "note": "writes above the 24 + 4 B algorithmic figure: the arena is written one 1.5 KB row per step of the WAVE (all 64 lanes' slots, also those of lanes whose node is shorter, whose band has fewer nodes, or that carry no job when a batch is spread over all wave slots), plus per-slice headers and node lists; reads: the traceback's column windows (24 B records in 192 B blocks), previous end words, graph records"
+     "note": "writes: the arena takes 24 B per band column in blocks of 8 columns per lane and node (only the blocks of lanes that have columns there are written), 4 B end words, per-slice headers and node lists, the traceback's node runs; reads: the traceback's column windows (24 B records in 192 B blocks), previous end words, graph records"
     }
     json.dump(t, open('$O/hbm_traffic.json', 'w'), indent=1)
 PY
