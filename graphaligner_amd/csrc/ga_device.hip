@@ -84,7 +84,7 @@ template <int N, int LW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) ga_lanes_kernel(gal::GaLanesLaunch L)
 {
 	using namespace gal;
-	__shared__ uint32_t lds[Lay<N>::WORDS * LW + LW * kStageWords64 * 2 + 64];  // tables, the staging image of LW lanes, the lanes' arena blocks
+	__shared__ uint32_t lds[Lay<N>::WORDS * LW + LW * kStageWords64 * 2 + 128];  // tables, the staging image of LW lanes, the lanes' arena blocks
 	const int lane = (int)threadIdx.x;
 	const WaveLayout lay = wave_layout<N>(L.cap_cols, L.cap_rows, L.max_slices, L.cap_moves, LW);
 	uint8_t* base = L.scratch + (uint64_t)blockIdx.x * L.wave_bytes;
@@ -433,7 +433,7 @@ struct DevBatch : GaBackendBatch
 		// (node runs are five words each: the staging plane holds a run per ten rows -- six times what a path over 64-bp nodes makes; a
 		// job that needs more reports GA_CAP_TRACE and climbs on)
 		P.cap_moves = maxRows * 2 + 1024;
-		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + LW * gal::kStageWords64 * 8 + 256;
+		const uint32_t ldsBytes = gal::Lay<N>::WORDS * LW * 4 + LW * gal::kStageWords64 * 8 + 512;
 		const uint32_t wavesPerCu = std::max<uint32_t>(1, std::min<uint32_t>(8, 163840u / ldsBytes));
 		// arena rows of a wave = the band columns of its lanes (in blocks of 8 per node), `rowsPerSlice` per lane and slice: sized for the
 		// lanes a wave will really carry

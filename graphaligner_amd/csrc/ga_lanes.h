@@ -115,9 +115,6 @@ template <int R> GAL_FN uint64_t rec_off(uint32_t row, int lane, uint32_t ls)
 #ifndef GAL_WINCAP
 #define GAL_WINCAP 24
 #endif
-#ifndef GAL_TOPUP
-#define GAL_TOPUP 4
-#endif
 constexpr int kStageWordsLane = 50;          // 32-bit words per lane of the staging image that follows the tables (64 lanes x kStageWords64 x 2 / 64)
 template <int N> struct Lay
 {
@@ -166,7 +163,7 @@ struct LaneMem
 	uint32_t* moves;
 	uint8_t* arena;
 	uint64_t* stage;              // device: the wave's LDS image of the open block of 8 arena rows
-	uint32_t* laneBlocks;         // device: LDS, per lane (first arena block of the node in hand) << 13 | its number of blocks
+	uint32_t* laneBlocks;         // device: LDS, per lane two words: the first arena block of the node in hand, its number of blocks
 	uint32_t usedChunks;          // device: 16-byte chunks of a block image that belong to lanes with a job (12 per lane)
 	int lane;
 	uint32_t flushPart, flushLane; // device: this thread's place in the block flush (tid % 12, tid / 12)
@@ -690,9 +687,8 @@ template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t chunk)
 		const uint32_t ln = (worker && g + 5u * (uint32_t)j < (uint32_t)LW) ? g + 5u * (uint32_t)j : 0u;
 		const uint64_t* sp = m.stage + ln * 25 + part * 2;
 		const uint64_t a = sp[0], b = sp[1];
-		const uint32_t pk = m.laneBlocks[ln];
-		const uint32_t last = (pk & 0x1fffu) - 1u;
-		const uint32_t at16 = ((pk >> 13) + (chunk < last ? chunk : last)) * 12u + part;          // in 16-byte units from the arena's start
+		const uint32_t blk0 = m.laneBlocks[2 * ln], last = m.laneBlocks[2 * ln + 1] - 1u;
+		const uint32_t at16 = (blk0 + (chunk < last ? chunk : last)) * 12u + part;                // in 16-byte units from the arena's start
 		uint64_t* d = (uint64_t*)(m.arena + (uint64_t)at16 * 16);
 		d[0] = a; d[1] = b;
 	}
@@ -828,7 +824,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 #ifndef GA_EMULATE
 		__builtin_amdgcn_wave_barrier();
 		// (a lane without a node this round points at the spare block behind the arena's rows)
-		if (m.tid < LW) m.laneBlocks[m.lane] = myBlocks ? ((firstBlock << 13) | myBlocks) : ((((capRows >> 3) + 1u) << 13) | 1u);
+		if (m.tid < LW) { m.laneBlocks[2 * m.lane] = myBlocks ? firstBlock : (capRows >> 3) + 1u; m.laneBlocks[2 * m.lane + 1] = myBlocks ? myBlocks : 1u; }
 		__builtin_amdgcn_wave_barrier();
 #endif
 		// operands of the first chunk (columns 0 .. U-1; column 0 itself comes from the node start below).  Requests are unconditional
@@ -1216,16 +1212,16 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		const uint32_t* h = m.hdr + (uint64_t)sIdx * kHdrWords * m.ls;
 		out.score = (int32_t)h[2 * m.ls];
 		uint32_t node = l.rd(tCN + (int)h[3 * m.ls]);
-		uint32_t offset = h[4 * m.ls];
+		int offset = (int)h[4 * m.ls];             // (a column of `node`; below 0 while a tight step has gone into the in-neighbour, see below)
 		uint32_t row = sIdx * W + (W - 1);
-		out.start_node = node; out.start_offset = offset; out.start_row = row;
+		out.start_node = node; out.start_offset = (uint32_t)offset; out.start_row = row;
 		// node runs instead of moves (L.emit_runs): a run is opened at the first cell met in a node (its last cell on the read) once
 		// the trace is below the rows that do not count, and written out with its first cell when the path leaves the node
 		bool tracing = true;
 		const bool emitRuns = L.emit_runs != 0;
 		const uint32_t traceRows = st.traceRows;
 		const uint32_t capRunWords = (L.cap_moves + 3) / 4 + 8;
-		uint32_t nRuns = 0, runLastOff = offset, runLastRow = row;
+		uint32_t nRuns = 0, runLastOff = (uint32_t)offset, runLastRow = row;
 		bool started = row < traceRows;
 		auto emitRun = [&](uint32_t n, uint32_t firstOff, uint32_t firstRow) {
 			if (5 * (nRuns + 1) > capRunWords) { status = GA_CAP_TRACE; tracing = false; return; }
@@ -1245,26 +1241,47 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			return true;
 		};
 		uint32_t pack = 0;
-		// Most steps stay inside a node and inside a slice.  Those run in a tight loop on two records held in registers (the current
-		// column and the one to its left) that are fed from a window of kWin consecutive columns of the node kept in LDS.  Everything
-		// rare -- filling the window, leaving a node through its first column, a step at the slice's first row, a change of
-		// slice -- is the general step below.  Rare per lane is not rare per wave: with 64 lanes some lane needs the general step
-		// in almost every iteration, so a lane that needs it WAITS while the others take fast steps, and the wave runs the general step
-		// for all waiting lanes at once when no lane can take a fast step any more; every general step also tops the window up, so the
-		// lanes leave it with about the same number of fast steps ahead of them.  (The order in which lanes step does not change
-		// what any of them computes; the host emulation simply runs each lane on its own.)
+#ifdef GA_DEBUG_SITE
+		uint32_t site = 0;                            // diagnostic builds: which of the traceback's assertions fired (summed per site in the pass statistics)
+#define GAL_SITE(n) site = (n)
+#else
+#define GAL_SITE(n)
+#endif
+		// Most steps stay inside a slice and move along a chain of nodes.  Those run in a tight loop on two records held in registers
+		// (the current column and the one to its left) that are fed from a window of kWin consecutive columns kept in LDS.  The window
+		// holds columns of the current node and -- when that node has exactly one in-neighbour, and the neighbour is in the slice --
+		// below column 0 the last columns of that in-neighbour: a step from column 0 into it is then the same arithmetic as a step inside
+		// a node (pickBacktracePredecessor with one in-neighbour, :512-556, tries the same three cells in the same order), and the
+		// tight loop takes it; the lane's coordinates follow at the next round.  Everything else is a ROUND of the wave after at most
+		// kBurst tight iterations: lanes that stand at a slice's first row, or at column 0 of a node whose way back is not one
+		// neighbour in the slice, take a DECISION (the general step: all in-neighbours, the slice above, the reference's asserts); every
+		// lane then has its window topped up.  Rare per lane is not rare per wave, so a lane that needs a decision WAITS while the others
+		// step, and the decision code runs for all waiting lanes at once; lanes meet a slice's first row at about the same time (a row
+		// per step, except for the few steps to the left), which is the one thing left that makes a lane wait.  (The order in which
+		// lanes step does not change what any of them computes; the host emulation simply runs each lane on its own.)
 		constexpr int kWin = Lay<N>::T_WINCOLS;
 		constexpr int tWIN = Lay<N>::T_WIN;
+		constexpr int kBurst = kWin - 4;
 		Col q0, q1;
 		q0.vp = q0.vn = 0; q0.before = 0; q1 = q0;
 		bool needSetup = true;
 		uint32_t slotRow = 0, recNode = 0xffffffffu, inDeg = 0;
 		uint32_t nb[4] = {0, 0, 0, 0}, nbLen[4] = {0, 0, 0, 0};
 		uint64_t firstCol = 0;
+		NodeRec nx = NodeRec();                       // the graph record of nxNode: the first in-neighbour of the node the lane was in when it was requested
+		uint32_t nxNode = 0xffffffffu, nxSlotRow = 0; // ... and the arena row of its column 0 in the current slice, when the window reaches into it
 		uint64_t wbases = 0;                          // the graph bases of the window's columns, 2 bits each from wLo up
-		uint32_t wLo = 1, wHi = 0;                    // columns of `node` (in slice sIdx) the window holds: [wLo, wHi], empty when wLo > wHi
-		auto winRead = [&](uint32_t o, Col& c) {
-			const int at = tWIN + (int)(o - wLo) * 5;
+		int wLo = 1, wHi = 0;                         // columns the window holds: [wLo, wHi] of `node`, columns below 0 being the in-neighbour's
+		                                              // (column c < 0 = its column nbLen[0] + c); empty when wLo > wHi
+		bool crossed = false, xStarted = false;       // a tight step went from column 0 into the in-neighbour: the rows around that step, and
+		uint32_t xRowBefore = 0, xRowAfter = 0;       // whether a run was open
+		uint32_t capMoves = L.cap_moves;
+		uint32_t roundsLeft = 2 * L.cap_moves + 4096;
+#ifndef GA_EMULATE
+		asm volatile("" : "+v"(capMoves));            // (kept in a vector register: as a scalar it is spilled with the launch block and read back lane by lane in every step)
+#endif
+		auto winRead = [&](int o, Col& c) {
+			const int at = tWIN + (o - wLo) * 5;
 			c.vp = ((uint64_t)l.rd(at + 1) << 32) | l.rd(at);
 			c.vn = ((uint64_t)l.rd(at + 3) << 32) | l.rd(at + 2);
 			c.before = (int)l.rd(at + 4);
@@ -1276,103 +1293,70 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			if ((len & 3) == 3) { m.moves[(uint64_t)(len >> 2) * m.ls] = pack; pack = 0; }
 			len++;
 		};
-		// after a change of node or slice: where the node's columns are, its graph record; and the window, whenever it does not reach
-		// at least a few columns to the left of the current one
-		auto ensure = [&]() {
-			if (needSetup)
-			{
-				const int slot = find_in(l, tCN, (int)nN, node);
-				if (slot < 0) { status = GA_ASSERTION; tracing = false; return; }       // assert(slice.scores.hasNode(nodeIndex)) (:498)
-				slotRow = curRow + l.rd(tCB + slot);
-				wLo = 1; wHi = 0;
-			}
-			const bool refill = !(offset >= wLo && offset <= wHi) || (wLo > 0 && offset - wLo < (uint32_t)GAL_TOPUP);
-			const uint32_t nLo = offset >= (uint32_t)(kWin - 1) ? offset - (uint32_t)(kWin - 1) : 0;
-			Col wc[kWin];
-			if (refill)
-			{
-#pragma unroll
-				for (int i = 0; i < kWin; i++) { uint32_t ew; wc[i].vp = 0; wc[i].vn = 0; wc[i].before = 0; if (nLo + (uint32_t)i <= offset) rec_load_col<8>(m, slotRow + nLo + (uint32_t)i, wc[i]); (void)ew; }
-			}
-			if (needSetup && node != recNode)
-			{
-				const uint32_t* rec = g_rec(g, node);
-				firstCol = ((uint64_t)rec[1] << 32) | rec[0];
-				inDeg = rec[3] & 0xffffu;
-#pragma unroll
-				for (int k = 0; k < 4; k++) { nb[k] = rec[8 + k]; nbLen[k] = rec[12 + k]; }
-				recNode = node;
-			}
-			needSetup = false;
-			if (refill)
-			{
-				wLo = nLo; wHi = offset;
-				{
-					const uint64_t col = firstCol + wLo;
-					const uint32_t* q = g.seq2 + (col >> 4);
-					const uint32_t sh = 2 * (uint32_t)(col & 15);
-					wbases = (((uint64_t)q[0] | ((uint64_t)q[1] << 32)) >> sh) | (sh ? (uint64_t)q[2] << (64 - sh) : 0ull);     // 32 columns
-				}
-#pragma unroll
-				for (int i = 0; i < kWin; i++)
-				{
-					if (wLo + (uint32_t)i <= wHi)
-					{
-						const int at = tWIN + i * 5;
-						l.wr(at, (uint32_t)wc[i].vp); l.wr(at + 1, (uint32_t)(wc[i].vp >> 32)); l.wr(at + 2, (uint32_t)wc[i].vn); l.wr(at + 3, (uint32_t)(wc[i].vn >> 32)); l.wr(at + 4, (uint32_t)wc[i].before);
-					}
-				}
-			}
-			winRead(offset, q0);
-			if (offset > wLo) winRead(offset - 1, q1);
+		// 32 bases from graph column `col` on, 2 bits each
+		auto bases32 = [&](uint64_t col, uint32_t w0, uint32_t w1, uint32_t w2) -> uint64_t {
+			const uint32_t sh = 2 * (uint32_t)(col & 15);
+			return (((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh) | (sh ? (uint64_t)w2 << (64 - sh) : 0ull);
 		};
-		ensure();
 #ifdef GA_EMULATE
 #define GAL_ANY(x) (x)
 #else
 #define GAL_ANY(x) (__ballot(x) != 0)
 #endif
+		bool firstRound = true;                       // the first round sets the lane up (no lane has a window yet)
 		uint64_t lapT = lap_clock();
 		while (GAL_ANY(tracing))
 		{
+			const bool first = firstRound;
+			firstRound = false;
 			{ const uint64_t t2 = lap_clock(); st.laps[1] += t2 - lapT; lapT = t2; }
-			// ---- fast steps: inside the node (offset > 0), inside the slice (r > 0), both columns in the window ----
-			// (the row masks and the current cell's score are carried from step to step: a step costs two cell values of the left column)
+			// ---- tight steps: inside the slice (r > 0), both columns in the window ----
+			// (the row masks and the current cell's score are carried from step to step: a step costs one cell value of the left column)
+			if (!first)
 			{
 				int r = (int)(row - sIdx * W);
 				uint64_t mR = r < 0 ? 0ull : r < 63 ? ~(~0ull << (r + 1)) : ~0ull;      // rows 0 .. r
-				uint64_t mU = r <= 0 ? 0ull : ~(~0ull << r);                               // rows 0 .. r - 1
 				int here = q0.before + __builtin_popcountll(q0.vp & mR) - __builtin_popcountll(q0.vn & mR);
 				// (straight-line, predicated: a lane that cannot step keeps its state through the selects; the column after next is
 				// requested from the window one step ahead and only looked at when the step has moved a column left)
 				Col q2;
 				winRead(((offset >= wLo + 2) & (offset <= wHi)) ? offset - 2 : wLo, q2);
-				while (true)
+				for (int it = 0; it < kBurst; it++)
 				{
-					const bool fast = tracing & (r > 0) & (offset > wLo) & (offset <= wHi) & (len + 8 < L.cap_moves);       // (& not &&: no branches)
+					const bool fast = tracing & (r > 0) & (offset > wLo) & (offset <= wHi) & (len + 8 < capMoves);       // (& not &&: no branches)
 					if (!GAL_ANY(fast)) break;
 #ifdef GA_STAMPS
 					st.laps[7] += 1ull << 32;
 #endif
+					// the three cells a step can go to: left (row r of the left column), diagonal (its row r - 1), up (row r - 1 of this column);
+					// row r - 1 of a column is its row r minus what the column's vertical bit r says
+					const int sr = r & 63;
 					const int horizontal = q1.before + __builtin_popcountll(q1.vp & mR) - __builtin_popcountll(q1.vn & mR);
-					const int diagonal = q1.before + __builtin_popcountll(q1.vp & mU) - __builtin_popcountll(q1.vn & mU);
-					const int up = q0.before + __builtin_popcountll(q0.vp & mU) - __builtin_popcountll(q0.vn & mU);
+					const int diagonal = horizontal - (int)((uint32_t)(q1.vp >> sr) & 1u) + (int)((uint32_t)(q1.vn >> sr) & 1u);
+					const int up = here - (int)((uint32_t)(q0.vp >> sr) & 1u) + (int)((uint32_t)(q0.vn >> sr) & 1u);
 					const int base = (int)(wbases >> (2 * ((offset - wLo) & 31))) & 3;
-					const int want = here - 1 + (int)((e[base] >> (r & 63)) & 1);      // the diagonal cell's score if the step is diagonal
+					const int want = here - 1 + (int)((e[base] >> sr) & 1);            // the diagonal cell's score if the step is diagonal
 					const bool left = horizontal == here - 1;
 					const bool diag = !left & (diagonal == want);
 					// the reference's asserts on the way (:557-588): a neighbour below what the recurrence allows, or no predecessor at all
 					const bool bad = (horizontal < here - 1) | (!left & (diagonal < want)) | (!left & !diag & (up != here - 1));
 					const bool ok = fast & !bad;
 					status = fast & bad ? GA_ASSERTION : status;
+#ifdef GA_DEBUG_SITE
+					site = fast & bad ? ((horizontal < here - 1) ? 1 : (!left & (diagonal < want)) ? 2 : 3) : site;
+#endif
 					tracing = tracing & !(fast & bad);
 					const bool colMove = ok & (left | diag), rowMove = ok & !left;
+					const bool crossNow = colMove & (offset == 0);                      // into the in-neighbour (only a window that reaches below 0 gets here)
+					xRowBefore = crossNow ? row : xRowBefore;
+					xStarted = crossNow ? started : xStarted;
+					crossed = crossed | crossNow;
 					here = ok ? (left ? horizontal : diag ? diagonal : up) : here;
 					row -= rowMove ? 1u : 0u;
 					r -= rowMove ? 1 : 0;
-					mR = rowMove ? mU : mR;
-					mU = rowMove ? mU >> 1 : mU;
-					offset -= colMove ? 1u : 0u;
+					mR = rowMove ? mR >> 1 : mR;
+					xRowAfter = crossNow ? row : xRowAfter;
+					offset -= colMove ? 1 : 0;
 					q0.vp = colMove ? q1.vp : q0.vp; q0.vn = colMove ? q1.vn : q0.vn; q0.before = colMove ? q1.before : q0.before;
 					q1.vp = colMove ? q2.vp : q1.vp; q1.vn = colMove ? q2.vn : q1.vn; q1.before = colMove ? q2.before : q1.before;
 					winRead(((offset >= wLo + 2) & (offset <= wHi)) ? offset - 2 : wLo, q2);
@@ -1380,7 +1364,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					{
 						// (the first cell below the rows that do not count opens the first run)
 						const bool begin = ok & !started & (row < traceRows);
-						runLastOff = begin ? offset : runLastOff;
+						runLastOff = begin ? (uint32_t)offset : runLastOff;
 						runLastRow = begin ? row : runLastRow;
 						started = started | begin;
 					}
@@ -1388,13 +1372,14 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				}
 			}
 			{ const uint64_t t2 = lap_clock(); st.laps[0] += t2 - lapT; lapT = t2; }
-			// ---- the general step, for every lane still tracing (none of them can take a fast step) ----
-			// Two round trips to HBM per step of the wave: everything a lane has to see before it can decide (its window when the step
+			// ---- the round, for every lane still tracing ----
+			// Two round trips to HBM per round of the wave: everything a lane has to see before it can decide (its window when the step
 			// left it, the in-neighbours' last columns at a node's first column, the columns of the slice above at a slice's first row,
 			// and the record of the first in-neighbour, where the path most likely goes) is requested together; after the decision, the
 			// new window, the tables of a new slice and the base words go together again.  Lanes that need nothing request a row that
-			// is always there: requests are wave-wide instructions either way, and a request behind a branch -- even a branch the whole
-			// wave takes together -- makes the compiler wait for everything outstanding where the branch ends.
+			// is always there: requests are wave-wide instructions either way, and a request behind a branch that only some lanes
+			// take makes the compiler wait for everything outstanding where the branch ends.  (The decision part as a whole sits behind a
+			// wave-uniform branch: most rounds only top the windows up.)
 #ifdef GA_STAMPS
 			st.laps[7] += 1;
 #endif
@@ -1402,21 +1387,54 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			{
 				const uint64_t g0 = lap_clock();
 				if (row == 0xffffffffu) { tracing = false; continue; }               // reached the row before the first one
-				if (len + 8 >= L.cap_moves) { status = GA_CAP_TRACE; tracing = false; continue; }
+				if (len + 8 >= capMoves) { status = GA_CAP_TRACE; tracing = false; continue; }
+				if (roundsLeft-- == 0) { status = GA_PUNT; tracing = false; continue; }          // (every round moves its lane; the bound is what ends the loop should one ever not)
+				const uint32_t safeRow = 0;
+				// a tight step took the lane into the in-neighbour: its coordinates follow (what the decision below does for a step it takes itself)
+				if (crossed)
+				{
+					const uint32_t oldNode = node, L0 = nbLen[0];
+					node = nb[0]; offset += (int)L0; wLo += (int)L0; wHi += (int)L0;
+					nodeSteps++;
+					slotRow = nxSlotRow;
+					firstCol = nx.firstCol; inDeg = nx.inDeg;                           // (a window only reaches into a neighbour whose record is here)
+#pragma unroll
+					for (int k = 0; k < 4; k++) { nb[k] = nx.nb[k]; nbLen[k] = nx.nbLen[k]; }
+					recNode = node;
+					crossed = false;
+					// (the run of the node left is written AFTER the lane's state has moved, and a run that does not fit ends the lane below:
+					// with `if (!tracing) continue;` between the two, hipcc 7.2 kept the OLD nb[] / nbLen[] for every lane that had a run to
+					// write -- profiles/r3_miscompile_normalization_isa.txt)
+					if (emitRuns)
+					{
+						if (xStarted) { emitRun(oldNode, 0, xRowBefore); runLastOff = L0 - 1; runLastRow = xRowAfter; }
+						else if (started) runLastOff += L0;                              // (the run was opened in the new node, at a column counted from the old one)
+					}
+				}
+				if (!tracing) continue;
 				if (inDeg > 4) { status = GA_PUNT; tracing = false; continue; }
 				const int r = (int)(row - sIdx * W);
-				const uint32_t safeRow = 0;
+				// can the window reach into the in-neighbour?  one in-neighbour, not the node itself, its record here, its columns in this slice
+				const bool chained = !first && inDeg == 1 && nb[0] != node && nxNode == nb[0];
+				const bool decision = !first && !(r > 0 && (offset > 0 || (chained && find_in(l, tCN, (int)nN, nb[0]) >= 0)));
+				bool changed = false;
+				NodeRec spec = NodeRec();
+				uint32_t specNode = 0xffffffffu;
+				if (GAL_ANY(decision))
+				{
+				if (decision)
+				{
 				const bool needWin = !(offset >= wLo && offset <= wHi && (offset == 0 || offset > wLo));
 				const bool atStart = offset == 0;
 				const bool atTop = r == 0 && sIdx > 0;
 				// (1) the window around the current column
 				Col wc[kWin];
 				uint32_t sq0 = 0, sq1 = 0, sq2 = 0;
-				const uint32_t nLoA = offset >= (uint32_t)(kWin - 1) ? offset - (uint32_t)(kWin - 1) : 0;
+				const int nLoA = offset >= kWin - 1 ? offset - (kWin - 1) : 0;
 				{
 #pragma unroll
-					for (int i = 0; i < kWin; i++) rec_load_col<8>(m, needWin && nLoA + (uint32_t)i <= offset ? slotRow + nLoA + (uint32_t)i : safeRow, wc[i]);
-					const uint64_t col = needWin ? firstCol + nLoA : 0ull;
+					for (int i = 0; i < kWin; i++) rec_load_col<8>(m, needWin && nLoA + i <= offset ? slotRow + (uint32_t)(nLoA + i) : safeRow, wc[i]);
+					const uint64_t col = needWin ? firstCol + (uint64_t)nLoA : 0ull;
 					const uint32_t* q = g.seq2 + (col >> 4);
 					sq0 = q[0]; sq1 = q[1]; sq2 = q[2];
 				}
@@ -1425,8 +1443,6 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 #pragma unroll
 				for (int k = 0; k < 4; k++) { nc[k].vp = nc[k].vn = 0; nc[k].before = 0; }
 				bool nIn[4] = {false, false, false, false};
-				NodeRec spec = NodeRec();
-				uint32_t specNode = 0xffffffffu;
 				{
 					uint32_t nbRow[4];
 #pragma unroll
@@ -1441,7 +1457,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					}
 #pragma unroll
 					for (int k = 0; k < 4; k++) rec_load_col<8>(m, nbRow[k], nc[k]);
-					if (atStart && inDeg > 0) specNode = nb[0];
+					if (atStart && inDeg > 0 && nb[0] != nxNode) specNode = nb[0];
 					loadRec(specNode != 0xffffffffu ? specNode : node, spec);
 				}
 				// (3) at a slice's first row: this column (U) and the column a diagonal step would reach (A) in the slice above
@@ -1453,7 +1469,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					if (atTop)
 					{
 						const int slU = find_in(l, tPN, (int)pN, node);
-						if (slU >= 0) { uIn = true; rowU = prvRow + l.rd(tPB + slU) + offset; }
+						if (slU >= 0) { uIn = true; rowU = prvRow + l.rd(tPB + slU) + (uint32_t)offset; }
 						if (offset > 0) { aIn = uIn; rowA = uIn ? rowU - 1 : safeRow; }
 						else if (inDeg > 0)
 						{
@@ -1468,12 +1484,11 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				if (needWin)
 				{
 					wLo = nLoA; wHi = offset;
-					const uint32_t sh = 2 * (uint32_t)((firstCol + wLo) & 15);
-					wbases = (((uint64_t)sq0 | ((uint64_t)sq1 << 32)) >> sh) | (sh ? (uint64_t)sq2 << (64 - sh) : 0ull);
+					wbases = bases32(firstCol + (uint64_t)wLo, sq0, sq1, sq2);
 #pragma unroll
 					for (int i = 0; i < kWin; i++)
 					{
-						if (wLo + (uint32_t)i <= wHi)
+						if (wLo + i <= wHi)
 						{
 							const int at = tWIN + i * 5;
 							l.wr(at, (uint32_t)wc[i].vp); l.wr(at + 1, (uint32_t)(wc[i].vp >> 32)); l.wr(at + 2, (uint32_t)wc[i].vn); l.wr(at + 3, (uint32_t)(wc[i].vn >> 32)); l.wr(at + 4, (uint32_t)wc[i].before);
@@ -1483,29 +1498,29 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					if (offset > wLo) winRead(offset - 1, q1);
 				}
 				const int here = col_value(q0.vp, q0.vn, q0.before, r);
-				if (emitRuns && !started && row < traceRows) { started = true; runLastOff = offset; runLastRow = row; }
+				if (emitRuns && !started && row < traceRows) { started = true; runLastOff = (uint32_t)offset; runLastRow = row; }
 				if (row == 0 && node == st.seedNode && (here == 0 || here == 1))                                                      // free start (:500)
 				{
-					if (emitRuns && started) emitRun(node, offset, row);
+					if (emitRuns && started) emitRun(node, (uint32_t)offset, row);
 					row = 0xffffffffu; tracing = false; continue;
 				}
 				const uint32_t rowBefore = row;
 				const int base = (int)(wbases >> (2 * (offset - wLo))) & 3;
 				const bool match = ((e[base] >> r) & 1) != 0;
 				int res = 0, via = 0;
-				const uint32_t curNode = node, curOffset = offset;
+				const uint32_t curNode = node, curOffset = (uint32_t)offset;
 				auto decide = [&](int horizontal, int diagonal, uint32_t un, uint32_t uo) -> int {
 					if (horizontal < here - 1) return -1;
-					if (horizontal == here - 1) { node = un; offset = uo; return 1; }
+					if (horizontal == here - 1) { node = un; offset = (int)uo; return 1; }
 					if (match)
 					{
 						if (diagonal < here) return -1;
-						if (diagonal == here) { node = un; offset = uo; row = row - 1; return 2; }
+						if (diagonal == here) { node = un; offset = (int)uo; row = row - 1; return 2; }
 					}
 					else
 					{
 						if (diagonal < here - 1) return -1;
-						if (diagonal == here - 1) { node = un; offset = uo; row = row - 1; return 2; }
+						if (diagonal == here - 1) { node = un; offset = (int)uo; row = row - 1; return 2; }
 					}
 					return 0;
 				};
@@ -1546,11 +1561,11 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					if (horizontal > here - 1) diagonal = r > 0 ? col_value(q1.vp, q1.vn, q1.before, r - 1) : aboveOf(aIn, ca, curNode);
 					res = decide(horizontal, diagonal, curNode, curOffset - 1);
 				}
-				if (res < 0) { status = GA_ASSERTION; tracing = false; continue; }
+				if (res < 0) { GAL_SITE(5); status = GA_ASSERTION; tracing = false; continue; }
 				if (res == 0)
 				{
 					const int up = r > 0 ? col_value(q0.vp, q0.vn, q0.before, r - 1) : aboveOf(uIn, cu, curNode);
-					if (up != here - 1) { status = GA_ASSERTION; tracing = false; continue; }              // assert(false) (:588)
+					if (up != here - 1) { GAL_SITE(6); status = GA_ASSERTION; tracing = false; continue; }              // assert(false) (:588)
 					row = row - 1;
 					res = 3;
 				}
@@ -1567,12 +1582,11 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					{
 						// (a self loop stays in its run, as consecutive cells of one node do in traceToAlignment :817-821)
 						if (started) { emitRun(curNode, curOffset, rowBefore); if (!tracing) continue; }
-						runLastOff = offset; runLastRow = row;
+						runLastOff = (uint32_t)offset; runLastRow = row;
 					}
-					if (!started && row < traceRows) { started = true; runLastOff = offset; runLastRow = row; }
+					if (!started && row < traceRows) { started = true; runLastOff = (uint32_t)offset; runLastRow = row; }
 				}
-				const uint64_t g1 = lap_clock();
-				const bool changed = res >= 2 && r == 0;                                // stepped into the slice above
+				changed = res >= 2 && r == 0;                                           // stepped into the slice above
 				if (changed)
 				{
 					sIdx--;
@@ -1582,42 +1596,68 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					pN = aN; prvRow = aRow;
 					needSetup = true;
 				}
-				// ---- where the lane stands now: the node's columns in the slice, the window, a new node's record, a new slice's tables ----
+				}
+				}
+				const uint64_t g1 = lap_clock();
+				// ---- where the lane stands now: the node's columns in the slice, a new node's record, the window, a new slice's tables ----
 				if (needSetup)
 				{
 					const int slot = find_in(l, tCN, (int)nN, node);
-					if (slot < 0) { status = GA_ASSERTION; tracing = false; continue; }       // assert(slice.scores.hasNode(nodeIndex)) (:498)
+					if (slot < 0) { GAL_SITE(4); status = GA_ASSERTION; tracing = false; continue; }       // assert(slice.scores.hasNode(nodeIndex)) (:498)
 					slotRow = curRow + l.rd(tCB + slot);
 					wLo = 1; wHi = 0;
 				}
-				const bool refill = !(offset >= wLo && offset <= wHi) || (wLo > 0 && offset - wLo < (uint32_t)GAL_TOPUP);
-				const uint32_t nLo = offset >= (uint32_t)(kWin - 1) ? offset - (uint32_t)(kWin - 1) : 0;
-				const bool newNode = needSetup && node != recNode;
-				if (newNode && node == specNode)
+				if (node != recNode && node == specNode)
 				{
 					firstCol = spec.firstCol; inDeg = spec.inDeg;
 #pragma unroll
 					for (int k = 0; k < 4; k++) { nb[k] = spec.nb[k]; nbLen[k] = spec.nbLen[k]; }
 					recNode = node;
 				}
-				const bool needRec = needSetup && node != recNode;
+				if (node != recNode && node == nxNode)
+				{
+					firstCol = nx.firstCol; inDeg = nx.inDeg;
+#pragma unroll
+					for (int k = 0; k < 4; k++) { nb[k] = nx.nb[k]; nbLen[k] = nx.nbLen[k]; }
+					recNode = node;
+				}
+				const bool needRec = node != recNode;
 				needSetup = false;
+				// the window: every column up to the current one that fits, reaching into the in-neighbour when the node is chained to it
+				int extSlot = -1;
+				if (!needRec && inDeg == 1 && nb[0] != node && nxNode == nb[0]) extSlot = find_in(l, tCN, (int)nN, nb[0]);
+				const int lowLimit = extSlot >= 0 ? -(int)nbLen[0] : 0;
+				if (extSlot >= 0) nxSlotRow = curRow + l.rd(tCB + extSlot);
+				const bool refill = !(offset >= wLo && offset <= wHi) || (wLo > lowLimit && offset - wLo < kWin - 1);
+				const int nLo = offset - (kWin - 1) > lowLimit ? offset - (kWin - 1) : lowLimit;
 				Col wd[kWin];
 				{
 #pragma unroll
-					for (int i = 0; i < kWin; i++) rec_load_col<8>(m, refill && nLo + (uint32_t)i <= offset ? slotRow + nLo + (uint32_t)i : safeRow, wd[i]);
+					for (int i = 0; i < kWin; i++)
+					{
+						const int c = nLo + i;
+						rec_load_col<8>(m, refill && c <= offset ? (c >= 0 ? slotRow + (uint32_t)c : nxSlotRow + nbLen[0] - (uint32_t)(-c)) : safeRow, wd[i]);
+					}
 				}
-				const bool seqNow = refill && !needRec;
-				sq0 = sq1 = sq2 = 0;
+				const int xLo = nLo > 0 ? nLo : 0;                                      // the window's first column of the node itself
+				const bool seqNow = refill && !needRec, seqNx = refill && nLo < 0;
+				uint32_t sq0 = 0, sq1 = 0, sq2 = 0, sy0 = 0, sy1 = 0, sy2 = 0;
+				const uint64_t colX = seqNow ? firstCol + (uint64_t)xLo : 0ull;
+				const uint64_t colY = seqNx ? nx.firstCol + nbLen[0] - (uint64_t)(-nLo) : 0ull;
 				{
-					const uint64_t col = seqNow ? firstCol + nLo : 0ull;
-					const uint32_t* q = g.seq2 + (col >> 4);
+					const uint32_t* q = g.seq2 + (colX >> 4);
 					sq0 = q[0]; sq1 = q[1]; sq2 = q[2];
+					const uint32_t* y = g.seq2 + (colY >> 4);
+					sy0 = y[0]; sy1 = y[1]; sy2 = y[2];
 				}
-				NodeRec fresh = NodeRec();
+				// the node's own record (entered through another in-neighbour than the first), and the record of ITS first in-neighbour
+				const bool wantNx = !needRec && inDeg >= 1 && nxNode != nb[0];
+				NodeRec fresh = NodeRec(), nxt = NodeRec();
 				loadRec(node, fresh);
+				loadRec(wantNx ? nb[0] : node, nxt);
 				uint32_t tbl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hN = 0, hRow = 0;
 				uint64_t ne[4] = {0, 0, 0, 0};
+				if (GAL_ANY(changed))
 				{
 					// the slice above the new one: the first four entries of its node list here, the rest (wide bands) in the loop below
 					const uint32_t* sn = m.snodes + (uint64_t)(changed && sIdx > 0 ? sIdx - 1 : 0) * 2 * N * m.ls;
@@ -1641,6 +1681,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 					if (sIdx > 1) { aN = hN; aRow = hRow; }
 					e[0] = ne[0]; e[1] = ne[1]; e[2] = ne[2]; e[3] = ne[3];
 				}
+				if (wantNx) { nx = nxt; nxNode = nb[0]; }
 				if (needRec)
 				{
 					firstCol = fresh.firstCol; inDeg = fresh.inDeg;
@@ -1651,7 +1692,7 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				if (GAL_ANY(refill && needRec))
 				{
 					// (a node entered through another in-neighbour than the first: its base words could only be requested now)
-					const uint64_t col = refill && needRec ? firstCol + nLo : 0ull;
+					const uint64_t col = refill && needRec ? firstCol + (uint64_t)xLo : 0ull;
 					const uint32_t* q = g.seq2 + (col >> 4);
 					const uint32_t t0 = q[0], t1 = q[1], t2 = q[2];
 					if (refill && needRec) { sq0 = t0; sq1 = t1; sq2 = t2; }
@@ -1659,12 +1700,13 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 				if (refill)
 				{
 					wLo = nLo; wHi = offset;
-					const uint32_t sh = 2 * (uint32_t)((firstCol + wLo) & 15);
-					wbases = (((uint64_t)sq0 | ((uint64_t)sq1 << 32)) >> sh) | (sh ? (uint64_t)sq2 << (64 - sh) : 0ull);
+					const uint64_t bx = bases32(firstCol + (uint64_t)xLo, sq0, sq1, sq2);
+					const int ny = xLo - nLo;                                           // columns of the in-neighbour in the window
+					wbases = ny > 0 ? ((bases32(colY, sy0, sy1, sy2) & ~(~0ull << (2 * ny))) | (bx << (2 * ny))) : bx;
 #pragma unroll
 					for (int i = 0; i < kWin; i++)
 					{
-						if (wLo + (uint32_t)i <= wHi)
+						if (wLo + i <= wHi)
 						{
 							const int at = tWIN + i * 5;
 							l.wr(at, (uint32_t)wd[i].vp); l.wr(at + 1, (uint32_t)(wd[i].vp >> 32)); l.wr(at + 2, (uint32_t)wd[i].vn); l.wr(at + 3, (uint32_t)(wd[i].vn >> 32)); l.wr(at + 4, (uint32_t)wd[i].before);
@@ -1677,6 +1719,10 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 			}
 		}
 #undef GAL_ANY
+#undef GAL_SITE
+#ifdef GA_DEBUG_SITE
+		if (status != GA_OK) out.stamps[site & 7] = 1;
+#endif
 		{ const uint64_t t2 = lap_clock(); st.laps[1] += t2 - lapT; lapT = t2; }
 		if (!emitRuns && (len & 3)) m.moves[(uint64_t)(len >> 2) * m.ls] = pack;
 		st.laps[3] = lap_clock();

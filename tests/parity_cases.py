@@ -389,6 +389,19 @@ def case_sparse_sharp_edges(lib_path=None):
     assert oras[0]["status"] == 1 and devs[0]["status"] == 1
 
 
+def case_long_reads_on_short_nodes(lib_path=None):
+    """50 kb reads on a chain of 8-bp nodes (the C5 shape at a size the oracle covers): bands of ~30 nodes, so the lanes = reads
+    kernel runs as <56,16> with arenas of millions of rows -- block numbers past 2^19, one block per node, lanes without a node in a
+    round (their staged image goes to the spare block behind the arena)"""
+    g = synth.linear_graph(400000, node_len=8, seed=5)
+    reads, seeds = synth.simulate_reads(g, 6, 50000, seed=6)
+    for trace in (True, False):
+        devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, 35, lib_path=lib_path, trace=trace)
+        for i, (d, o) in enumerate(zip(devs, oras)):
+            pc.compare_read(d, o if trace else dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "50 kb read %d on 8-bp nodes" % i)
+    assert all(o["status"] == 0 for o in oras)
+
+
 def case_trace_pool_overflow(lib_path=None, monkeypatch=None):
     """a trace pool far too small for the batch: jobs that find no room report a capacity miss; every job that reports success has
     its moves intact (claims commit only when they fit, so no two regions overlap) and equals the oracle"""

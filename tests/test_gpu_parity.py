@@ -112,5 +112,9 @@ def test_randomised_campaign():
     assert stats["compared"] >= 300
 
 
+def test_long_reads_on_short_nodes():
+    cases.case_long_reads_on_short_nodes()
+
+
 def test_trace_pool_overflow():
     cases.case_trace_pool_overflow()
