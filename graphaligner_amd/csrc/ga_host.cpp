@@ -313,6 +313,7 @@ struct ga_batch
 	std::vector<RowFill> fills;         // where every job's rows come from
 	std::vector<uint8_t> rows;          // row codes, built when a kernel that wants them is about to run (see buildRows)
 	std::atomic<int> anyInvalidRow{0};    // some read has a character outside IUPAC (its results need the TraceItem pass)
+	std::unique_ptr<std::atomic<uint8_t>[]> readInvalid;   // ... per read: a row of one of its jobs has such a character (noted while the match words are built)
 	std::unique_ptr<uint64_t[]> eq;       // match words per slice (not cleared first: every slice is written by the host threads)
 	size_t eqWords = 0;
 	std::vector<GaJob> jobs;
@@ -853,6 +854,8 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	const auto tp1 = std::chrono::steady_clock::now();
 	b->eqWords = (rowsTotal / W + 1) * 5;       // match words per slice for the lanes = reads kernel
 	b->eq.reset(new uint64_t[b->eqWords]);
+	b->readInvalid.reset(new std::atomic<uint8_t>[nReads + 1]);
+	for (size_t i = 0; i <= nReads; i++) b->readInvalid[i].store(0, std::memory_order_relaxed);
 	for (int k = 0; k < 5; k++) b->eq[b->eqWords - 5 + k] = 0;              // (the slack slice behind the last job)
 	forEachFill(b, [&](const RowFill& f, const ReadSeq& seq) {
 		// 64 row codes at a time, straight into the slice's match words
@@ -868,7 +871,7 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 			for (uint64_t k = full; k < (uint64_t)W; k++) buf[k] = padCode;
 			uint64_t* words = b->eq.get() + (f.off + r0) / W * 5;
 			ga_build_eq_words(buf, W, words);
-			if (words[4] & 8u) b->anyInvalidRow.store(1, std::memory_order_relaxed);
+			if (words[4] & 8u) { b->anyInvalidRow.store(1, std::memory_order_relaxed); b->readInvalid[f.read].store(1, std::memory_order_relaxed); }
 		}
 	});
 	// Node runs instead of moves from the traceback when no result of the batch needs a cell list: no TraceItem lists wanted, every
@@ -1015,7 +1018,9 @@ int ga_batch_collect(ga_batch_t* b, ga_results_t** out)
 		if (o.status != GA_OK) return false;
 		rr.reserved = (int32_t)o.reserved2;                                      // which kernel pass finished the job (0 = the first)
 		const ReadSeq& seq = b->seqs[ri];
-		for (char c : seq) if (tables().rowCode[(uint8_t)c] & GA_ROW_INVALID) return false;     // (the reference's eager TraceItem pass asserts on these)
+		// (the reference's eager TraceItem pass asserts on characters outside IUPAC: with the one forward job from the first base the
+		// job's rows are the whole read, and the match-word pass has noted whether one of them is such a character)
+		if (b->readInvalid[ri].load(std::memory_order_relaxed)) return false;
 		if (o.n_valid == 0) { rr.column_updates += o.n_columns; rr.status = GA_S_OK; return true; }     // nothing kept: both parts fail (rr stays failed)
 		const uint64_t traceable = seq.size() - sp.pos - g.dbgOverlap;
 		const uint64_t dummyEndAsIndex = g.bases.size() - 1;
