@@ -52,8 +52,8 @@ def _usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=50000)
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--genome", type=int, default=4641652)

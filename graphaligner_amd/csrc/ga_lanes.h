@@ -459,6 +459,10 @@ template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, La
 	curNodes.load(l, LY::C_NODE, cn);
 	prevNodes.load(l, LY::P_NODE, pn);
 	uint64_t outAll[4] = {0, 0, 0, 0};                // kRegs: 4 out-neighbour slots of 4 bits (15 = none) per node, 4 nodes per word
+	// kRegs: is the band one simple path?  the only in-band out-neighbour per node (4 bits each, 15 = none), nodes with an in-band in-neighbour
+	uint64_t succAll = ~0ull;
+	uint32_t hasPred = 0;
+	bool simple = true;
 	if (cn > 0) loadRec9(0, cur);
 	for (int s = 0; s < cn; s++)
 	{
@@ -485,6 +489,17 @@ template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, La
 			const uint64_t field = (uint64_t)nibbles << (16 * (s & 3));
 #pragma unroll
 			for (int w = 0; w < 4; w++) outAll[w] |= (s >> 2) == w ? field : 0ull;
+			uint32_t nOut = 0, nIn = 0, only = 15u;
+#pragma unroll
+			for (uint32_t e = 0; e < 4; e++)
+			{
+				const uint32_t x = (nibbles >> (4 * e)) & 15u;
+				if (x != 15u) { nOut++; only = x; }
+				if (((inCur >> (8 * e)) & 0xffu) != kNone) nIn++;
+			}
+			simple = simple && nOut <= 1 && nIn <= 1;
+			succAll = (succAll & ~(15ull << (4 * s))) | ((uint64_t)only << (4 * s));
+			hasPred |= nIn ? 1u << s : 0u;
 		}
 		else
 		{
@@ -500,6 +515,39 @@ template <int N> GAL_FN int band_order(const GaDevGraph& g, const LaneMem& m, La
 	{ const uint64_t t2 = lap_clock(); st.blaps[3] += t2 - bt; bt = t2; }
 	if constexpr (kRegs)
 	{
+		// A band that is one simple path (every node at most one in-band out- and in-neighbour, one node without an in-band
+		// in-neighbour, all nodes reached from it) has one emission order whatever the search's roots are: a node is emitted when its only
+		// way on has been, so the path comes out from its end to its head.  The search below is only run when some lane's band is not that.
+		bool path = false;
+		uint64_t along = 0;                                 // the path's slots from its head, 4 bits each
+		{
+			const uint32_t heads = ~hasPred & ((1u << cn) - 1u);
+			if (simple && heads != 0 && (heads & (heads - 1u)) == 0)
+			{
+				int v = __builtin_ctz(heads), k = 0;
+				bool ended = false;
+				while (k < cn && !ended)
+				{
+					along |= (uint64_t)v << (4 * k);
+					k++;
+					const int nx = (int)(succAll >> (4 * v)) & 15;
+					ended = nx == 15;
+					v = nx;
+				}
+				path = ended && k == cn;
+			}
+		}
+#ifdef GA_EMULATE
+		const bool search = !path;
+#else
+		const bool search = __ballot(!path) != 0;
+#endif
+		if (!search)
+		{
+			for (int k = 0; k < cn; k++) l.wrb(LY::X_ORD, LY::OB_POST + k, (uint32_t)(along >> (4 * (cn - 1 - k))) & 15u);
+			{ const uint64_t t2 = lap_clock(); st.blaps[4] += t2 - bt; bt = t2; }
+			return GA_OK;
+		}
 		// the same depth-first search with its state in registers: colour 2 bits per slot, the stack's slots and edge cursors 4 bits per level
 		uint32_t color = 0;
 		uint64_t stSlot = 0, stCur = 0;
