@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="diagnostic build with per-phase cycle stamps (not a timed build)")
     ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
     ap.add_argument("--accuracy", type=int, default=256, help="reads scored against the simulator's true paths with the reference's criterion (CompareAlignments.cpp)")
-    ap.add_argument("--pipeline-chunks", type=int, default=4, help="chunks of the batch's size run through the overlapped host pipeline for detail.pipelined_host_to_host_Gbp_s (0 = skip)")
+    ap.add_argument("--pipeline-chunks", type=int, default=12, help="chunks of the batch's size run through the overlapped host pipeline for detail.pipelined_host_to_host_Gbp_s (0 = skip)")
     ap.add_argument("--check", type=int, default=64, help="reads compared with the oracle after the run (includes failed / later-pass reads)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: ONE read set of --reads reads for the whole job, chunks pulled by the ranks from the shared queue "
                                                           "(sharding.align_queued); default is weak scaling, --reads per GPU")

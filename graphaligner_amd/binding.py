@@ -253,10 +253,15 @@ class Batch:
         finally:
             self.L.ga_results_free(out)
 
+    def close(self):
+        """free the batch now (its device buffers and its copy of the reads go back to the graph's pools)"""
+        if self.h:
+            self.L.ga_batch_free(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            if self.h:
-                self.L.ga_batch_free(self.h)
+            self.close()
         except Exception:
             pass
 

@@ -9,7 +9,9 @@
 #endif
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
+#include <memory>
 #include <vector>
 
 #include "ga_types.h"
@@ -64,11 +66,42 @@ struct GaRunStats
 	uint64_t stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic builds: summed shader cycles per phase
 };
 
-class GaBackendGraph { public: virtual ~GaBackendGraph() {} };
+// What the match words are built from when the back end builds them itself (GaBackendGraph::buildsMatchWords): the batch's copy of
+// the reads and, per job, where its rows come from -- rows k < n are read characters (forward: seq[seq_off + pos + k] through rowCode;
+// backward: seq[seq_off + n - 1 - k] through rowCodeRc), rows n .. padded - 1 are padCode; the job's first slice is eq_slice.
+struct GaEqFill { uint64_t seq_off, eq_slice; uint32_t pos, n, padded, backward; };
+struct GaEqSource
+{
+	const char* seq = nullptr; size_t seqBytes = 0;
+	const GaEqFill* fills = nullptr; size_t nFills = 0;
+	const uint8_t* rowCode = nullptr; const uint8_t* rowCodeRc = nullptr;       // 256 entries each
+	uint8_t padCode = 0;
+};
+
+class GaBackendGraph
+{
+public:
+	virtual ~GaBackendGraph() {}
+	// true: ga_backend_create_batch wants a GaEqSource and builds the match words on its side (the product: a kernel over the uploaded
+	// reads); false: it wants the finished words (the host emulation of tests/emul)
+	virtual bool buildsMatchWords() const { return false; }
+	// host memory for a batch's copy of the reads (the product: pinned blocks from a pool, so that their upload is one DMA transfer)
+	virtual std::shared_ptr<char> hostBlock(size_t bytes)
+	{
+		void* mem = nullptr;
+		const size_t two = (size_t)2 << 20;
+		if (posix_memalign(&mem, two, (bytes + two - 1) & ~(two - 1)) != 0) return std::shared_ptr<char>();
+		return std::shared_ptr<char>((char*)mem, [](char* p) { free(p); });
+	}
+};
 class GaBackendBatch
 {
 public:
 	virtual ~GaBackendBatch() {}
+	// back ends that build the match words: per fill of the GaEqSource, 1 when one of its rows is a character outside IUPAC
+	virtual const std::vector<uint8_t>* invalidFills() const { return nullptr; }
+	// GaRunConfig::emit_runs as it ended up (a back end that builds the match words clears it when a row is such a character)
+	virtual bool emittingRuns() const = 0;
 	virtual int run() = 0;                                                   // device work only; returns ga_status
 	// moves of job i: (*traceBytes)[outs[i].trace_off ..+trace_len); the bytes stay the backend's (valid until fetchDone or the next fetch)
 	virtual int fetch(std::vector<GaJobOut>& outs, const uint8_t** traceBytes, uint64_t* nBytes) = 0;
@@ -83,7 +116,8 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& g, const GaHmmTables&
 // rows: the row codes (one byte per padded read base) are only needed by the wave-per-read ladder kernels, so they are built and uploaded
 // on demand: the provider returns them (building them at its first call)
 typedef std::function<const std::vector<uint8_t>&()> GaRowsProvider;
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobs,
+// (eq or src: the finished words, or what a back end that builds them itself builds them from)
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const uint64_t* eq, const GaEqSource* src, size_t eqWords, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status);
 
 // the match words of ga_backend_create_batch from the row codes

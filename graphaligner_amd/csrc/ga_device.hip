@@ -154,8 +154,77 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 	}
 }
 
+// ---- the match words of the lanes = reads kernel, built from the reads' bytes (ga_backend.h: GaEqSource) -------------------------
+// One wave per job (its rows come from one read, forwards from the seed or backwards before it); lane r of the wave holds row r of the
+// slice in hand: the character's row code through a 512-byte table in LDS, four ballots = the slice's match words against A, C, G, T
+// (characterMatch, GraphAligner.h:2039-2110; what the reference builds as EqVector, :2338-2351), one more for "a row outside IUPAC".
+__global__ void __launch_bounds__(64) ga_eq_words_kernel(const uint8_t* __restrict__ seq, const GaEqFill* __restrict__ fills, uint32_t nFills, const uint8_t* __restrict__ lut,
+                                                         uint32_t padCode, uint64_t* __restrict__ eq, uint8_t* __restrict__ flags)
+{
+	__shared__ uint8_t t[512];
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t i = lane; i < 512; i += 64) t[i] = lut[i];
+	__syncthreads();
+	for (uint32_t fi = blockIdx.x; fi < nFills; fi += gridDim.x)
+	{
+		const GaEqFill f = fills[fi];
+		const uint8_t* s = seq + f.seq_off;
+		bool bad = false;
+		for (uint32_t r0 = 0; r0 < f.padded; r0 += 64)
+		{
+			const uint32_t k = r0 + lane;
+			uint32_t code = padCode;
+			if (k < f.n) code = f.backward ? t[256 + s[f.n - 1 - k]] : t[s[f.pos + k]];
+			const uint64_t e0 = __ballot(code & 1u), e1 = __ballot(code & 2u), e2 = __ballot(code & 4u), e3 = __ballot(code & 8u);
+			const uint64_t inv = __ballot(code & GA_ROW_INVALID);
+			const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)code, 63);
+			const uint64_t meta = (uint64_t)((last >> 4) & 7u) | (inv ? 8u : 0u);     // exact-compare code of the slice's last row | a row outside IUPAC
+			if (lane < 5) eq[(f.eq_slice + r0 / 64) * 5 + lane] = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : lane == 3 ? e3 : meta;
+			bad = bad || inv != 0;
+		}
+		if (lane == 0) flags[fi] = bad ? 1 : 0;
+	}
+}
+
+// pinned host blocks for the batches' copies of the reads (page-locking half a GB per batch costs more than copying it): a block goes
+// back to the pool when the last holder -- the batch, or results whose edit sequences point into it -- lets go of it
+struct PinnedPool
+{
+	std::mutex lock;
+	std::vector<std::pair<size_t, char*>> idle;
+	~PinnedPool() { for (auto& b : idle) hipHostFree(b.second); }
+};
+
 struct DevGraph : GaBackendGraph
 {
+	std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
+	bool buildsMatchWords() const override { return true; }
+	std::shared_ptr<char> hostBlock(size_t bytes) override
+	{
+		const size_t two = (size_t)2 << 20;
+		bytes = (bytes + two - 1) & ~(two - 1);
+		std::shared_ptr<PinnedPool> pool = pinned;
+		char* p = nullptr;
+		size_t cap = 0;
+		{
+			std::lock_guard<std::mutex> guard(pool->lock);
+			size_t best = pool->idle.size();
+			for (size_t i = 0; i < pool->idle.size(); i++)
+				if (pool->idle[i].first >= bytes && pool->idle[i].first <= 2 * bytes + two && (best == pool->idle.size() || pool->idle[i].first < pool->idle[best].first)) best = i;
+			if (best != pool->idle.size()) { cap = pool->idle[best].first; p = pool->idle[best].second; pool->idle.erase(pool->idle.begin() + (long)best); }
+		}
+		if (!p)
+		{
+			hipSetDevice(device);
+			if (hipHostMalloc((void**)&p, bytes, hipHostMallocDefault) != hipSuccess) return GaBackendGraph::hostBlock(bytes);      // (pageable memory: the upload is then a staged copy)
+			cap = bytes;
+		}
+		return std::shared_ptr<char>(p, [pool, cap](char* q) {
+			std::lock_guard<std::mutex> guard(pool->lock);
+			if (pool->idle.size() < 6) pool->idle.emplace_back(cap, q); else hipHostFree(q);
+		});
+	}
+
 	int device = 0;
 	GaDevGraph g;
 	GaHmmTables* hmm = nullptr;
@@ -322,7 +391,11 @@ struct DevBatch : GaBackendBatch
 		return 0;
 	}
 
-	int init(const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobsIn)
+	std::vector<uint8_t> badFills;     // per fill of the GaEqSource: a row outside IUPAC
+	const std::vector<uint8_t>* invalidFills() const override { return &badFills; }
+	bool emittingRuns() const override { return cfg.emit_runs != 0; }
+
+	int init(const uint64_t* eq, const GaEqSource* src, size_t eqWords, const std::vector<GaJob>& jobsIn)
 	{
 		HIP_OK(hipSetDevice(g->device));
 		// (non-blocking: a copy or a kernel of this batch must not wait for another batch's kernel through the null stream)
@@ -340,7 +413,30 @@ struct DevBatch : GaBackendBatch
 		GaJob* dJobs; uint64_t* eqDev;
 		if (alloc(&eqDev, eqWords)) return GA_E_DEVICE;
 		if (alloc(&dJobs, jobs.size())) return GA_E_DEVICE;
-		HIP_OK(hipMemcpyAsync(eqDev, eq, eqWords * 8, hipMemcpyHostToDevice, stream));
+		if (!src && !eq) return GA_E_INVALID;
+		if (src)
+		{
+			// the reads go up as they are (one transfer from the batch's pinned copy) and a kernel turns them into the match words
+			uint8_t *dSeq, *dLut, *dFlags; GaEqFill* dFills;
+			if (alloc(&dSeq, src->seqBytes + 64) || alloc(&dFills, src->nFills) || alloc(&dLut, 512) || alloc(&dFlags, src->nFills)) return GA_E_DEVICE;
+			uint8_t lut[512];
+			memcpy(lut, src->rowCode, 256); memcpy(lut + 256, src->rowCodeRc, 256);
+			HIP_OK(hipMemcpyAsync(dSeq, src->seq, src->seqBytes, hipMemcpyHostToDevice, stream));
+			HIP_OK(hipMemcpyAsync(dFills, src->fills, src->nFills * sizeof(GaEqFill), hipMemcpyHostToDevice, stream));
+			HIP_OK(hipMemcpyAsync(dLut, lut, 512, hipMemcpyHostToDevice, stream));
+			HIP_OK(hipMemsetAsync(eqDev + (eqWords - 5), 0, 40, stream));             // (the slack slice behind the last job)
+			badFills.assign(src->nFills, 0);
+			if (src->nFills)
+			{
+				const uint32_t blocks = (uint32_t)std::min<size_t>(src->nFills, (size_t)g->cus * 64);
+				hipLaunchKernelGGL(ga_eq_words_kernel, dim3(blocks), dim3(64), 0, stream, dSeq, dFills, (uint32_t)src->nFills, dLut, (uint32_t)src->padCode, eqDev, dFlags);
+				HIP_OK(hipGetLastError());
+				HIP_OK(hipMemcpyAsync(badFills.data(), dFlags, src->nFills, hipMemcpyDeviceToHost, stream));
+			}
+			HIP_OK(hipStreamSynchronize(stream));                                      // (lut is on this stack; the flags decide emit_runs below)
+			for (uint8_t f : badFills) if (f) { cfg.emit_runs = 0; break; }
+		}
+		else HIP_OK(hipMemcpyAsync(eqDev, eq, eqWords * 8, hipMemcpyHostToDevice, stream));
 		HIP_OK(hipMemcpyAsync(dJobs, jobs.data(), jobs.size() * sizeof(GaJob), hipMemcpyHostToDevice, stream));
 		L.rows = nullptr;
 		L.jobs = dJobs;
@@ -684,14 +780,14 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, GaRowsProvider rows, const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobs,
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* graph, GaRowsProvider rows, const uint64_t* eq, const GaEqSource* src, size_t eqWords, const std::vector<GaJob>& jobs,
                                         const GaRunConfig& cfg, int* status)
 {
 	DevBatch* b = new DevBatch();
 	b->g = static_cast<DevGraph*>(graph);
 	b->cfg = cfg;
 	b->rowsProvider = rows;
-	int s = b->init(eq, eqWords, jobs);
+	int s = b->init(eq, src, eqWords, jobs);
 	if (s) { delete b; *status = s; return nullptr; }
 	*status = 0;
 	return b;

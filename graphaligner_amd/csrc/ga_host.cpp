@@ -764,13 +764,10 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		std::vector<uint64_t> at(nReads + 1, 0);
 		for (size_t i = 0; i < nReads; i++) at[i + 1] = at[i] + reads[i].length;
 		b->seqBufBytes = (size_t)at[nReads] + 64;
-		void* mem = nullptr;
-		if (posix_memalign(&mem, 2u << 20, (b->seqBufBytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1)) != 0) { delete b; return GA_E_INVALID; }
-		b->seqBuf = (char*)mem;
-		b->seqKeep = std::shared_ptr<char>((char*)mem, [](char* p) { free(p); });
-#ifdef MADV_HUGEPAGE
-		madvise(mem, (b->seqBufBytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1), MADV_HUGEPAGE);
-#endif
+		// (from the back end: the product hands out pinned blocks of a pool, so that the upload of the reads is one DMA transfer)
+		b->seqKeep = g->device->hostBlock(b->seqBufBytes);
+		if (!b->seqKeep) { delete b; return GA_E_INVALID; }
+		b->seqBuf = b->seqKeep.get();
 		size_t nThreads = usableCores();
 		if (const char* e = getenv("GA_HOST_THREADS")) nThreads = (size_t)atoi(e);
 		nThreads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nThreads, 16), nReads / 256 + 1));
@@ -853,9 +850,25 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	b->rowsTotal = rowsTotal;
 	const auto tp1 = std::chrono::steady_clock::now();
 	b->eqWords = (rowsTotal / W + 1) * 5;       // match words per slice for the lanes = reads kernel
-	b->eq.reset(new uint64_t[b->eqWords]);
 	b->readInvalid.reset(new std::atomic<uint8_t>[nReads + 1]);
 	for (size_t i = 0; i <= nReads; i++) b->readInvalid[i].store(0, std::memory_order_relaxed);
+	// The product's back end builds the match words itself, by a kernel over the uploaded reads (the words are 0.6 bytes per base of
+	// table look-ups and bit gathering: 26 ms on 16 host threads for the benchmark batch, nothing on the device); the host builder
+	// below is what the host emulation of tests/emul gets its words from.
+	const bool deviceWords = g->device->buildsMatchWords();
+	std::vector<GaEqFill> eqFills;
+	if (deviceWords)
+	{
+		eqFills.resize(fills.size());
+		for (size_t k = 0; k < fills.size(); k++)
+		{
+			const RowFill& f = fills[k];
+			eqFills[k] = GaEqFill{(uint64_t)(b->seqs[f.read].data() - b->seqBuf), f.off / W, (uint32_t)f.pos, (uint32_t)f.n, (uint32_t)f.padded, f.backward ? 1u : 0u};
+		}
+	}
+	else
+	{
+	b->eq.reset(new uint64_t[b->eqWords]);
 	for (int k = 0; k < 5; k++) b->eq[b->eqWords - 5 + k] = 0;              // (the slack slice behind the last job)
 	forEachFill(b, [&](const RowFill& f, const ReadSeq& seq) {
 		// 64 row codes at a time, straight into the slice's match words
@@ -874,6 +887,7 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 			if (words[4] & 8u) { b->anyInvalidRow.store(1, std::memory_order_relaxed); b->readInvalid[f.read].store(1, std::memory_order_relaxed); }
 		}
 	});
+	}
 	// Node runs instead of moves from the traceback when no result of the batch needs a cell list: no TraceItem lists wanted, every
 	// read with one seed at its first base (one forward job: no backward part to mirror, no later seed to test against the cells
 	// of an earlier one, GraphAligner.h:423-429), no character whose TraceItem the reference would assert on
@@ -881,6 +895,8 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 		// ... and a graph of long nodes (the shape the lanes = reads kernel is the first pass for): a path then changes node every few
 		// dozen rows and its runs are a fraction of its moves; on graphs chopped into short nodes moves are the smaller output
 		const double meanNode = g->nodeCount() > 2 ? (double)g->bases.size() / (double)(g->nodeCount() - 2) : 64.0;
+		// (with the words built by the back end, whether a row is such a character is known when the batch has been created: the back
+		// end clears the flag then)
 		bool runs = (flags & GA_F_TRACE) == 0 && b->anyInvalidRow.load() == 0 && meanNode >= 40 && !(getenv("GA_RUNS") && atoi(getenv("GA_RUNS")) == 0);
 		for (size_t i = 0; i < nReads && runs; i++) if (b->reads[i].nSeeds > 1) runs = false;
 		for (const SeedPlan& sp : b->seeds) if (sp.bwJob >= 0 || (sp.fwJob >= 0 && sp.pos != 0)) { runs = false; break; }
@@ -888,8 +904,19 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 	}
 	int status = GA_S_OK;
 	const auto tp2 = std::chrono::steady_clock::now();
-	b->dev = ga_backend_create_batch(g->device, [b]() -> const std::vector<uint8_t>& { buildRows(b); return b->rows; }, b->eq.get(), b->eqWords, b->jobs, b->cfg, &status);
+	GaEqSource src;
+	src.seq = b->seqBuf; src.seqBytes = b->seqBufBytes;
+	src.fills = eqFills.data(); src.nFills = eqFills.size();
+	src.rowCode = T.rowCode; src.rowCodeRc = T.rowCodeRc; src.padCode = T.rowCode[(uint8_t)'N'];
+	b->dev = ga_backend_create_batch(g->device, [b]() -> const std::vector<uint8_t>& { buildRows(b); return b->rows; }, b->eq.get(), deviceWords ? &src : nullptr, b->eqWords,
+	                                 b->jobs, b->cfg, &status);
 	if (!b->dev) { delete b; return status ? status : GA_E_DEVICE; }
+	if (const std::vector<uint8_t>* bad = b->dev->invalidFills())
+	{
+		for (size_t k = 0; k < fills.size() && k < bad->size(); k++)
+			if ((*bad)[k]) { b->anyInvalidRow.store(1, std::memory_order_relaxed); b->readInvalid[fills[k].read].store(1, std::memory_order_relaxed); }
+	}
+	b->cfg.emit_runs = b->dev->emittingRuns() ? 1u : 0u;
 	if (getenv("GA_DEBUG_COLLECT"))
 	{
 		const auto tp3 = std::chrono::steady_clock::now();

@@ -81,6 +81,13 @@ def run_overlapped(graph, inputs, bandwidth, ramp=0, flags=0, summary=False, gam
             return key, graph.prepare(what[0], what[1], bandwidth, ramp, flags)
         return key, graph.prepare(what, None, bandwidth, ramp, flags)
 
+    def finish(batch):
+        # (the batch is freed as soon as its results are out: its device buffers and its pinned copy of the reads serve the next one)
+        try:
+            return batch.collect_gam() if gam else batch.collect(summary)
+        finally:
+            batch.close()
+
     done = []                         # (key, future of its results)
     with ThreadPoolExecutor(max_workers=2) as pool:
         nxt = pool.submit(prep)
@@ -91,7 +98,7 @@ def run_overlapped(graph, inputs, bandwidth, ramp=0, flags=0, summary=False, gam
             key, batch = got
             nxt = pool.submit(prep)                                      # built and uploaded while this input runs
             batch.run()
-            done.append((key, pool.submit(batch.collect_gam) if gam else pool.submit(batch.collect, summary)))     # assembled while the next input runs
+            done.append((key, pool.submit(finish, batch)))                # assembled while the next input runs
         return [(k, f.result()) for k, f in done]
 
 

@@ -189,6 +189,7 @@ struct EmulBatch : GaBackendBatch
 		return 0;
 	}
 	GaRunStats stats() const override { GaRunStats s; s.jobs_retried = retried; s.slots = 1; return s; }
+	bool emittingRuns() const override { return cfg.emit_runs != 0; }
 };
 
 }  // namespace
@@ -212,7 +213,7 @@ GaBackendGraph* ga_backend_upload_graph(const GaFlatGraph& flat, const GaHmmTabl
 	return g;
 }
 
-GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const uint64_t* eq, size_t eqWords, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
+GaBackendBatch* ga_backend_create_batch(GaBackendGraph* g, GaRowsProvider rows, const uint64_t* eq, const GaEqSource*, size_t eqWords, const std::vector<GaJob>& jobs, const GaRunConfig& cfg, int* status)
 {
 	EmulBatch* b = new EmulBatch();
 	b->g = static_cast<EmulGraph*>(g);
