@@ -90,6 +90,8 @@ def main(argv=None, quiet=False):
             reads[k] = b.decode()
         if args.only is not None and trial not in args.only:
             continue
+        if trial % 25 == 0:
+            print("trial %d of %d, %d reads, %d mismatches, %.0f s" % (trial, args.trials, stats["reads"], stats["mismatches"], time.time() - t0), file=sys.stderr, flush=True)
         devs, oras = pc.run_both(g.nodes, g.edges, reads, seeds, bw, ramp=ramp, lib_path=lib, trace=not args.no_trace)
         if args.no_trace:
             oras = [dict(o, trace=np.zeros((0, 7), dtype=np.int64)) for o in oras]
