@@ -752,6 +752,11 @@ GAL_FN uint32_t wave_alloc(uint32_t mine, uint32_t top, uint32_t& first)
 }
 #endif
 
+template <int N> constexpr bool kEqInLds = NodeRegs<N>::kOn && N >= 8;       // (needs 8 free words per lane: C_OUT is only written by the wide variants)
+template <int N> GAL_FN uint64_t eq_from_lds(const Lds& l, int base)
+{
+	return (uint64_t)l.rd(Lay<N>::C_OUT + 2 * base) | ((uint64_t)l.rd(Lay<N>::C_OUT + 2 * base + 1) << 32);
+}
 GAL_FN uint64_t eq_for(uint64_t e0, uint64_t e1, uint64_t e2, uint64_t e3, int base)
 {
 	const uint64_t lo = (base & 1) ? e1 : e0, hi = (base & 1) ? e3 : e2;
@@ -989,6 +994,13 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 #pragma unroll
 			for (int i = 0; i < U; i++) pe2[i] = pendSafe[(uint64_t)(w0 + U + (uint32_t)i) * m.ls];
 			{ const uint32_t* q = seqSafe + (((sh0 >> 1) + w0 + U) >> 4); bw2 = (uint64_t)q[0] | ((uint64_t)q[1] << 32); }
+			// (narrow variant: the chunk's match words are read from the LDS table up front, so that no column waits for its own)
+			uint64_t eqw[U];
+			if constexpr (kEqInLds<N>)
+			{
+#pragma unroll
+				for (int i = 0; i < U; i++) eqw[i] = eq_from_lds<N>(l, (int)(bw >> (sh + 2 * i)) & 3);
+			}
 #pragma unroll
 			for (int i = 0; i < U; i++)
 			{
@@ -1006,7 +1018,7 @@ GAL_FN void fill_slice(const GaDevGraph& g, const LaneMem& m, LaneState& st, uin
 					int calc = c.before + 1;
 					if (existsW) { const int viaDiag = above2 + 1 - (aboveEq ? 1 : 0); calc = calc < viaDiag ? calc : viaDiag; }    // :1361-1370
 					const bool reenter = calc > pv;                                // :1541-1546 (pv = INF when the node is new to the band)
-					column_step(c, eq_for(e0, e1, e2, e3, base), !exists, reenter ? pv : calc);
+					column_step(c, kEqInLds<N> ? eqw[i] : eq_for(e0, e1, e2, e3, base), !exists, reenter ? pv : calc);
 					exists = reenter || existsW;
 					above2 = ew_end2(peRaw);
 				}
@@ -1096,6 +1108,14 @@ template <int N> GAL_FN void lane_band(const GaLanesLaunch& L, const LaneMem& m,
 	if (rc == GA_OK) rc = band_order<N>(L.graph, m, st);
 	if (rc == GA_OK && (meta & 8u)) rc = GA_ASSERTION;                            // characterMatch default branch (:2104-2106)
 	if (rc != GA_OK) { st.status = rc; st.live = false; st.totalCols = 0; }
+	if constexpr (kEqInLds<N>)
+	{
+		// the slice's four match words as a table (the words of C_OUT, free in the narrow variant once the band is put together): the
+		// fill picks a column's word by its base with one LDS read instead of a chain of selects
+		const Lds& l = m.lds;
+#pragma unroll
+		for (int k = 0; k < 4; k++) { l.wr(Lay<N>::C_OUT + 2 * k, (uint32_t)e[k]); l.wr(Lay<N>::C_OUT + 2 * k + 1, (uint32_t)(e[k] >> 32)); }
+	}
 }
 
 // after the fill: HMM step, stop test, bookkeeping, and the slice becomes the state (getSqrtSlices, :2571-2856)

@@ -14,10 +14,10 @@ echo "pmc done"
 cp $O/hbm_traffic.json profiles/r3_hbm_traffic.json      # (so that the lines below carry this build's traffic figure)
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench done"
-python3 bench.py --graph bubbles --genome 12100000 --reads 20000 --cpu-sample 0 --check 32 --steps 2 --warmup 1 > $O/bench_bubbles.json 2> $O/bench_bubbles.err
-GA_DEBUG_PASSES=1 python3 bench.py --graph dense --node-len 32 --genome 3000000 --reads 16000 --read-len 15000 --errors 0.02,0.08,0.05 --cpu-sample 0 --check 32 --steps 2 --warmup 1 > $O/bench_dense.json 2> $O/bench_dense.err
-GA_LANES=1 python3 bench.py --graph bubbles --genome 12100000 --reads 20000 --cpu-sample 0 --check 32 --steps 2 --warmup 1 > $O/bench_bubbles_lanes_first.json 2> $O/bench_bubbles_lanes_first.err
-GA_LANES=1 python3 bench.py --graph dense --node-len 32 --genome 3000000 --reads 16000 --read-len 15000 --errors 0.02,0.08,0.05 --cpu-sample 0 --check 32 --steps 2 --warmup 1 > $O/bench_dense_lanes_first.json 2> $O/bench_dense_lanes_first.err
+python3 bench.py --graph bubbles --genome 12100000 --reads 20000 --cpu-sample 0 --check 32 --steps 6 --warmup 2 > $O/bench_bubbles.json 2> $O/bench_bubbles.err
+GA_DEBUG_PASSES=1 python3 bench.py --graph dense --node-len 32 --genome 3000000 --reads 16000 --read-len 15000 --errors 0.02,0.08,0.05 --cpu-sample 0 --check 32 --steps 6 --warmup 2 > $O/bench_dense.json 2> $O/bench_dense.err
+GA_LANES=1 python3 bench.py --graph bubbles --genome 12100000 --reads 20000 --cpu-sample 0 --check 32 --steps 6 --warmup 2 > $O/bench_bubbles_lanes_first.json 2> $O/bench_bubbles_lanes_first.err
+GA_LANES=1 python3 bench.py --graph dense --node-len 32 --genome 3000000 --reads 16000 --read-len 15000 --errors 0.02,0.08,0.05 --cpu-sample 0 --check 32 --steps 6 --warmup 2 > $O/bench_dense_lanes_first.json 2> $O/bench_dense_lanes_first.err
 python3 - <<PY
 import json
 lines = {}
