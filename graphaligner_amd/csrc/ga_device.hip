@@ -186,6 +186,17 @@ __global__ void __launch_bounds__(64) ga_eq_words_kernel(const uint8_t* __restri
 	}
 }
 
+// every job's output record starts a run as "not run" (what a job keeps when no pass ever picks it up)
+__global__ void ga_outs_init_kernel(GaJobOut* outs, uint32_t n)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	GaJobOut o;
+	memset(&o, 0, sizeof(o));
+	o.status = GA_NOT_RUN;
+	outs[i] = o;
+}
+
 // pinned host blocks for the batches' copies of the reads (page-locking half a GB per batch costs more than copying it): a block goes
 // back to the pool when the last holder -- the batch, or results whose edit sequences point into it -- lets go of it
 struct PinnedPool
@@ -352,6 +363,7 @@ struct DevBatch : GaBackendBatch
 	uint32_t* dList = nullptr;  // job list of the current pass
 	size_t dListCap = 0;
 	std::vector<GaJobOut> outs;
+	bool outsLocked = false;
 	std::vector<uint32_t> orderHost;   // all jobs, longest first (the device queues hand them out in this order)
 	std::vector<uint8_t> passOf;       // which pass of the last run finished each job (0 = the first)
 	int passNo = 0;
@@ -364,6 +376,7 @@ struct DevBatch : GaBackendBatch
 	{
 		hipSetDevice(g->device);
 		if (hostFromPool) g->giveHost();
+		if (outsLocked) hipHostUnregister(outs.data());
 		for (auto& a : allocs) g->giveBlock(a.second, a.first);
 		if (privateScratch) hipFree(privateScratch);
 		if (evA) hipEventDestroy(evA);
@@ -449,6 +462,10 @@ struct DevBatch : GaBackendBatch
 		dListCap = std::max<size_t>(jobs.size(), 1);
 		if (alloc(&dList, dListCap)) return GA_E_DEVICE;
 		if (alloc(&L.outs, jobs.size())) return GA_E_DEVICE;
+		// (the host copy of the records is page-locked: they come back after every pass, 128 bytes per job)
+		outs.assign(jobs.size(), GaJobOut{});
+		for (auto& o : outs) o.status = GA_NOT_RUN;
+		outsLocked = !outs.empty() && hipHostRegister(outs.data(), outs.size() * sizeof(GaJobOut), hipHostRegisterDefault) == hipSuccess;
 		if (alloc(&L.next_job, 4)) return GA_E_DEVICE;
 		if (alloc(&L.trace_top, 2)) return GA_E_DEVICE;
 		uint64_t totalRows = 0;
@@ -639,12 +656,12 @@ struct DevBatch : GaBackendBatch
 	{
 		HIP_OK(hipSetDevice(g->device));
 		st = GaRunStats();
-		outs.assign(jobs.size(), GaJobOut{});
 		passOf.assign(jobs.size(), 0);
 		passNo = 0;
 		if (jobs.empty()) return 0;
-		for (auto& o : outs) o.status = GA_NOT_RUN;
-		HIP_OK(hipMemcpyAsync(L.outs, outs.data(), outs.size() * sizeof(GaJobOut), hipMemcpyHostToDevice, stream));
+		// (the records are initialised on the device and come back whole after every pass: nothing to prepare or upload here)
+		hipLaunchKernelGGL(ga_outs_init_kernel, dim3((uint32_t)((jobs.size() + 255) / 256)), dim3(256), 0, stream, L.outs, (uint32_t)jobs.size());
+		HIP_OK(hipGetLastError());
 		HIP_OK(hipMemsetAsync(L.trace_top, 0, 16, stream));
 		// ---- first the lanes = reads kernel: one job per lane.  Its LDS tables hold 16, 32 or 64 band nodes per lane (4, 2, 1
 		// waves per CU); the starting size follows the graph's mean node length, and jobs a size cannot hold move to the next ----
