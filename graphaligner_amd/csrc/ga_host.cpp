@@ -781,15 +781,21 @@ int ga_batch_prepare(const ga_graph_t* g, const ga_read_t* reads, size_t nReads,
 				{
 					if (reads[i].length) memcpy(b->seqBuf + at[i], reads[i].sequence, reads[i].length);
 					b->seqs[i] = ReadSeq(b->seqBuf + at[i], reads[i].length);
+					b->names[i] = reads[i].name ? reads[i].name : "";
 				}
 			});
 		}
 		for (auto& th : pool) th.join();
 	}
 	const auto tpc = std::chrono::steady_clock::now();
+	{
+		const size_t nSeeds = seedOffsets[nReads] - seedOffsets[0];
+		b->seeds.reserve(nSeeds);
+		b->jobs.reserve(2 * nSeeds);
+		fills.reserve(2 * nSeeds);
+	}
 	for (size_t i = 0; i < nReads; i++)
 	{
-		b->names[i] = reads[i].name ? reads[i].name : "";
 		const ReadSeq& seq = b->seqs[i];
 		b->reads[i].firstSeed = b->seeds.size();
 		b->reads[i].nSeeds = seedOffsets[i + 1] - seedOffsets[i];
