@@ -158,8 +158,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 // One wave per job (its rows come from one read, forwards from the seed or backwards before it); lane r of the wave holds row r of the
 // slice in hand: the character's row code through a 512-byte table in LDS, four ballots = the slice's match words against A, C, G, T
 // (characterMatch, GraphAligner.h:2039-2110; what the reference builds as EqVector, :2338-2351), one more for "a row outside IUPAC".
+// The row codes themselves (one byte per padded row: what the wave-per-read kernels read) are written on the way.
 __global__ void __launch_bounds__(64) ga_eq_words_kernel(const uint8_t* __restrict__ seq, const GaEqFill* __restrict__ fills, uint32_t nFills, const uint8_t* __restrict__ lut,
-                                                         uint32_t padCode, uint64_t* __restrict__ eq, uint8_t* __restrict__ flags)
+                                                         uint32_t padCode, uint64_t* __restrict__ eq, uint8_t* __restrict__ flags, uint8_t* __restrict__ rows)
 {
 	__shared__ uint8_t t[512];
 	const uint32_t lane = threadIdx.x;
@@ -175,6 +176,7 @@ __global__ void __launch_bounds__(64) ga_eq_words_kernel(const uint8_t* __restri
 			const uint32_t k = r0 + lane;
 			uint32_t code = padCode;
 			if (k < f.n) code = f.backward ? t[256 + s[f.n - 1 - k]] : t[s[f.pos + k]];
+			rows[f.eq_slice * 64 + k] = (uint8_t)code;
 			const uint64_t e0 = __ballot(code & 1u), e1 = __ballot(code & 2u), e2 = __ballot(code & 4u), e3 = __ballot(code & 8u);
 			const uint64_t inv = __ballot(code & GA_ROW_INVALID);
 			const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)code, 63);
@@ -396,6 +398,7 @@ struct DevBatch : GaBackendBatch
 	int ensureRows()
 	{
 		if (L.rows) return 0;
+		if (builtRows) { L.rows = builtRows; return 0; }                          // (written by the match-word kernel)
 		const std::vector<uint8_t>& rows = rowsProvider();
 		uint8_t* dRows;
 		if (alloc(&dRows, rows.size())) return GA_E_DEVICE;
@@ -404,6 +407,7 @@ struct DevBatch : GaBackendBatch
 		return 0;
 	}
 
+	uint8_t* builtRows = nullptr;      // the row codes, when the match-word kernel wrote them
 	std::vector<uint8_t> badFills;     // per fill of the GaEqSource: a row outside IUPAC
 	const std::vector<uint8_t>* invalidFills() const override { return &badFills; }
 	bool emittingRuns() const override { return cfg.emit_runs != 0; }
@@ -430,8 +434,11 @@ struct DevBatch : GaBackendBatch
 		if (src)
 		{
 			// the reads go up as they are (one transfer from the batch's pinned copy) and a kernel turns them into the match words
-			uint8_t *dSeq, *dLut, *dFlags; GaEqFill* dFills;
-			if (alloc(&dSeq, src->seqBytes + 64) || alloc(&dFills, src->nFills) || alloc(&dLut, 512) || alloc(&dFlags, src->nFills)) return GA_E_DEVICE;
+			uint8_t *dSeq, *dLut, *dFlags, *dRows; GaEqFill* dFills;
+			const size_t rowBytes = (eqWords / 5) * 64 + 64;                         // (+ slack so a 64-byte row load never leaves the buffer)
+			if (alloc(&dSeq, src->seqBytes + 64) || alloc(&dFills, src->nFills) || alloc(&dLut, 512) || alloc(&dFlags, src->nFills) || alloc(&dRows, rowBytes)) return GA_E_DEVICE;
+			HIP_OK(hipMemsetAsync(dRows + rowBytes - 128, 0, 128, stream));
+			builtRows = dRows;
 			uint8_t lut[512];
 			memcpy(lut, src->rowCode, 256); memcpy(lut + 256, src->rowCodeRc, 256);
 			HIP_OK(hipMemcpyAsync(dSeq, src->seq, src->seqBytes, hipMemcpyHostToDevice, stream));
@@ -442,7 +449,7 @@ struct DevBatch : GaBackendBatch
 			if (src->nFills)
 			{
 				const uint32_t blocks = (uint32_t)std::min<size_t>(src->nFills, (size_t)g->cus * 64);
-				hipLaunchKernelGGL(ga_eq_words_kernel, dim3(blocks), dim3(64), 0, stream, dSeq, dFills, (uint32_t)src->nFills, dLut, (uint32_t)src->padCode, eqDev, dFlags);
+				hipLaunchKernelGGL(ga_eq_words_kernel, dim3(blocks), dim3(64), 0, stream, dSeq, dFills, (uint32_t)src->nFills, dLut, (uint32_t)src->padCode, eqDev, dFlags, dRows);
 				HIP_OK(hipGetLastError());
 				HIP_OK(hipMemcpyAsync(badFills.data(), dFlags, src->nFills, hipMemcpyDeviceToHost, stream));
 			}
@@ -659,7 +666,9 @@ struct DevBatch : GaBackendBatch
 		passOf.assign(jobs.size(), 0);
 		passNo = 0;
 		if (jobs.empty()) return 0;
-		// (the records are initialised on the device and come back whole after every pass: nothing to prepare or upload here)
+		// (the records are initialised on the device and come back whole after every pass: nothing to upload here; the host copy's
+		// statuses are what the passes select their jobs by, so a batch that is run again starts from "not run" here too)
+		for (auto& o : outs) o.status = GA_NOT_RUN;
 		hipLaunchKernelGGL(ga_outs_init_kernel, dim3((uint32_t)((jobs.size() + 255) / 256)), dim3(256), 0, stream, L.outs, (uint32_t)jobs.size());
 		HIP_OK(hipGetLastError());
 		HIP_OK(hipMemsetAsync(L.trace_top, 0, 16, stream));

@@ -402,6 +402,26 @@ def case_long_reads_on_short_nodes(lib_path=None):
     assert all(o["status"] == 0 for o in oras)
 
 
+def case_batch_run_twice(lib_path=None):
+    """a prepared batch can be run again (bench.py alternates two): every pass must start from scratch -- the second run's results equal
+    the first's and the oracle's, on a long-node and on a short-node graph (lanes = reads first / wave per read first)"""
+    from graphaligner_amd import binding
+    for graph in (synth.linear_graph(20000, node_len=64, seed=81), synth.SynthGraph(synth.random_genome(20000, 82), node_len=16, snp_every=30, indel_every=300, seed=83)):
+        reads, seeds = synth.simulate_reads(graph, 12, 1500, seed=84)
+        g = binding.Graph(graph.nodes, graph.edges, lib_path=lib_path)
+        og = ob.OracleGraph(graph.nodes, graph.edges)
+        for flags in (binding.GA_F_TRACE, 0):
+            b = g.prepare(reads, [[s] for s in seeds], 35, 0, flags)
+            b.run()
+            first = b.collect()
+            b.run()
+            second = b.collect()
+            for i, (x, y) in enumerate(zip(first, second)):
+                assert x["status"] == y["status"] and x["score"] == y["score"] and x["mappings"] == y["mappings"], ("second run differs", i)
+                o = og.align(reads[i], [seeds[i]], 35)
+                pc.compare_read(y, o if flags else dict(o, trace=np.zeros((0, 7), dtype=np.int64)), "second run, read %d" % i)
+
+
 def case_trace_pool_overflow(lib_path=None, monkeypatch=None):
     """a trace pool far too small for the batch: jobs that find no room report a capacity miss; every job that reports success has
     its moves intact (claims commit only when they fit, so no two regions overlap) and equals the oracle"""

@@ -77,5 +77,9 @@ def test_sparse_sharp_edges(lib):
     cases.case_sparse_sharp_edges(lib)
 
 
+def test_batch_run_twice(lib):
+    cases.case_batch_run_twice(lib)
+
+
 def test_trace_pool_overflow(lib):
     cases.case_trace_pool_overflow(lib)

@@ -116,5 +116,9 @@ def test_long_reads_on_short_nodes():
     cases.case_long_reads_on_short_nodes()
 
 
+def test_batch_run_twice():
+    cases.case_batch_run_twice()
+
+
 def test_trace_pool_overflow():
     cases.case_trace_pool_overflow()
