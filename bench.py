@@ -306,7 +306,7 @@ def main():
     }
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm), host cores, bounded sample ----
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and world == 1:            # (on rank 0 of a single-GPU run only)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding as ob
         cores = _usable_cores()
@@ -319,8 +319,12 @@ def main():
                                "value_1_thread": round(b1["aligned_bp"] / b1["seconds"] / 1e9, 6),
                                "sample": "first %d reads of the same batch, %d threads popping reads from a shared queue (Aligner.cpp:285-298), %.1f s; 1 thread: first %d reads, %.1f s"
                                          % (n, cores, b["seconds"], n1, b1["seconds"])}
-        # spot check against the oracle: a regular sample plus every read that failed or was not finished by the first pass
+    # spot check against the oracle: a regular sample plus every read that failed or was not finished by the first pass
+    if args.check > 0 and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding as ob
         import parity_common as pc
+        og = ob.OracleGraph(g.nodes, g.edges)
         k = min(args.check, len(reads))
         if k:
             special = [int(i) for i in np.nonzero((summary["failed"] != 0) | (summary["status"] != 0) | (summary["reserved"] != 0))[0][:k // 2]]
