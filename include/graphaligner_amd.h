@@ -18,9 +18,11 @@
  * The library needs a gfx950 device: ga_graph_upload / ga_batch_run return GA_E_NO_DEVICE
  * when none is usable.  There is no CPU fallback.
  *
- * Memory the library keeps between calls: a scratch pool and a pinned download buffer per uploaded graph (freed with the graph),
- * and up to GA_RESULT_POOL_MB (default 4096) of recycled result arrays per process.  Environment knobs, none of them needed:
- * GA_HOST_THREADS (host threads for job building and result assembly; default: all, at most 64), GA_RESULT_POOL_MB,
+ * Memory the library keeps between calls: a scratch pool, a pinned download buffer, idle device blocks of finished batches and up to
+ * six pinned blocks for the batches' copies of the reads per uploaded graph (freed with the graph; a batch's copy of its reads is also
+ * what its results' edit_bytes point into, so such a block lives until both the batch and its results are freed), and up to
+ * GA_RESULT_POOL_MB (default 4096) of recycled result arrays per process.  Environment knobs, none of them needed:
+ * GA_HOST_THREADS (host threads for job building and result assembly; default: the CPUs the process may use), GA_RESULT_POOL_MB,
  * GA_LANES=1/0 (force / forbid the lanes = reads kernel as the first pass; default by the graph's mean node length),
  * GA_LANES_SPREAD=0 (full waves instead of spreading a small batch over all wave slots), GA_DEBUG_PASSES / GA_DEBUG_COLLECT
  * (one line per kernel pass / per host stage on stderr).
