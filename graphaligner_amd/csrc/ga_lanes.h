@@ -692,6 +692,12 @@ GAL_FN int col_value(uint64_t vp, uint64_t vn, int before, int row)            /
 	return before + __builtin_popcountll(vp & mask) - __builtin_popcountll(vn & mask);
 }
 
+// a store of data nobody reads again soon
+#if defined(GA_EMULATE)
+#define GAL_NT_STORE(p, v) (*(p) = (v))
+#else
+#define GAL_NT_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 // (records are 8-byte aligned: three 64-bit words)
 template <int R> GAL_FN void rec_store(const LaneMem& m, uint32_t row, const Col& c, uint32_t endWord)
 {
@@ -722,6 +728,9 @@ template <int R> GAL_FN void rec_load_col(const LaneMem& m, uint32_t row, Col& c
 // belongs to lane q / 12 (rec_off<8>: lane-major inside a block)
 template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t chunk)
 {
+#ifdef GA_EXPERIMENT_NOFLUSH
+	return;                                     // (diagnostic builds only: how long the fill takes when its records never leave the LDS)
+#endif
 	__builtin_amdgcn_wave_barrier();
 	// chunk `chunk` of the nodes in hand: lane ln's 8 records (192 B) go to ITS block first + chunk.  Twelve threads write one lane's
 	// block (16 B each); thread t serves lanes t / 12, t / 12 + 5, ... -- five lanes per store instruction, every LDS address a constant of
@@ -738,7 +747,9 @@ template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t chunk)
 		const uint32_t blk0 = m.laneBlocks[2 * ln], last = m.laneBlocks[2 * ln + 1] - 1u;
 		const uint32_t at16 = (blk0 + (chunk < last ? chunk : last)) * 12u + part;                // in 16-byte units from the arena's start
 		uint64_t* d = (uint64_t*)(m.arena + (uint64_t)at16 * 16);
-		d[0] = a; d[1] = b;
+		// (non-temporal: written once and read by the traceback much later -- 31.0 -> 29.7 ms against plain stores; the same hint on
+		// the end words, which the next slice reads back, or on any of the loads costs 3-6 ms, profiles/r3_ab_nontemporal.txt)
+		GAL_NT_STORE(d, a); GAL_NT_STORE(d + 1, b);
 	}
 	__builtin_amdgcn_wave_barrier();
 }
