@@ -749,7 +749,11 @@ template <int LW> GAL_FN void stage_flush(const LaneMem& m, uint32_t chunk)
 		uint64_t* d = (uint64_t*)(m.arena + (uint64_t)at16 * 16);
 		// (non-temporal: written once and read by the traceback much later -- 31.0 -> 29.7 ms against plain stores; the same hint on
 		// the end words, which the next slice reads back, or on any of the loads costs 3-6 ms, profiles/r3_ab_nontemporal.txt)
+#ifdef GA_PLAIN_ARENA_STORES
+		d[0] = a; d[1] = b;                          // (A/B builds)
+#else
 		GAL_NT_STORE(d, a); GAL_NT_STORE(d + 1, b);
+#endif
 	}
 	__builtin_amdgcn_wave_barrier();
 }

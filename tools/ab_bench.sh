@@ -4,7 +4,7 @@
 set -e
 mkdir -p gpurun_out
 for n in "$@"; do
-  timeout -k 10 300 python bench.py --steps 3 --warmup 1 --cpu-sample 0 --accuracy 0 --check 16 --lib build/ab/libga_$n.so $AB_FLAGS > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err
+  timeout -k 10 300 python bench.py --steps ${AB_STEPS:-3} --warmup 1 --cpu-sample 0 --accuracy 0 --check 16 --lib build/ab/libga_$n.so $AB_FLAGS > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err
   python - <<PY
 import json
 d=json.loads(open('gpurun_out/ab_$n.json').read().strip().splitlines()[-1])
