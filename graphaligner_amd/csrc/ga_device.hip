@@ -341,12 +341,14 @@ struct DevGraph : GaBackendGraph
 struct Knobs
 {
 	int lanes = -1;                 // -1: by graph shape
+	int spread = 1;                 // 1: a small batch is spread over all wave slots; 0: full waves; k > 1: k jobs per wave (GA_LANES_SPREAD, for experiments)
 	bool debugPasses = false;
 	uint64_t tracePoolBytes = 0;    // 0: sized from the batch
 	Knobs()
 	{
 		if (const char* e = getenv("GA_LANES")) lanes = atoi(e) != 0 ? 1 : 0;
 		debugPasses = getenv("GA_DEBUG_PASSES") != nullptr;
+		if (const char* e = getenv("GA_LANES_SPREAD")) spread = atoi(e);
 		if (const char* t = getenv("GA_TEST_TRACE_POOL_BYTES")) tracePoolBytes = (uint64_t)atoll(t) & ~3ull;
 	}
 };
@@ -564,10 +566,13 @@ struct DevBatch : GaBackendBatch
 		gal::WaveLayout lay = layoutFor(LW);
 		const uint64_t fit = scratchBudget() / std::max<uint64_t>(lay.bytes, 1);
 		const uint64_t slotsHere = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)g->cus * wavesPerCu, std::max<uint64_t>(fit, 64)));
-		// a batch that does not fill every wave slot with LW jobs is spread over all of them: a wave's steps cost the same with
-		// fewer lanes, and fewer lanes wait for each other less
+		// a SMALL batch is spread over all wave slots: a wave's steps cost the same with fewer lanes, and fewer lanes wait for each
+		// other less.  A batch that gives at least six of ten slots a full wave runs in full waves: round 3's kernel is more sensitive
+		// to the waves it shares its CU's memory path with than to the lanes it waits for (50 000 reads: 782 full waves 28.5 ms,
+		// 1 021 waves of 49 reads 30.2 ms on the same box, profiles/r3_ab_lanes_per_wave.txt; round 2's kernel: the other way round)
 		uint32_t lanesPer = LW;
-		if (list.size() < slotsHere * LW)
+		if (knobs.spread > 1) lanesPer = (uint32_t)std::min<int>(LW, knobs.spread);
+		else if (knobs.spread && list.size() * 10 < slotsHere * LW * 6)
 			lanesPer = (uint32_t)std::min<uint64_t>(LW, std::max<uint64_t>(8, (list.size() + slotsHere - 1) / slotsHere));
 		P.lanes_per_wave = lanesPer;
 		lay = layoutFor(lanesPer);

@@ -24,7 +24,7 @@
  * GA_RESULT_POOL_MB (default 4096) of recycled result arrays per process.  Environment knobs, none of them needed:
  * GA_HOST_THREADS (host threads for job building and result assembly; default: the CPUs the process may use), GA_RESULT_POOL_MB,
  * GA_LANES=1/0 (force / forbid the lanes = reads kernel as the first pass; default by the graph's mean node length),
- * GA_LANES_SPREAD=0 (full waves instead of spreading a small batch over all wave slots), GA_DEBUG_PASSES / GA_DEBUG_COLLECT
+ * GA_LANES_SPREAD=0 / k (full waves / k reads per wave instead of spreading a small batch over all wave slots), GA_DEBUG_PASSES / GA_DEBUG_COLLECT
  * (one line per kernel pass / per host stage on stderr).
  */
 #ifndef GRAPHALIGNER_AMD_H

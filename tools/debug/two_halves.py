@@ -19,7 +19,7 @@ h1 = graph.prepare(reads[:n // 2], seeds[:n // 2], 35, 0, 0)
 h2 = graph.prepare(reads[n // 2:], seeds[n // 2:], 35, 0, 0)
 for b in (full, h1, h2):
     b.run()
-K = 6
+K = int(os.environ.get("K", "6"))
 t0 = time.perf_counter()
 for _ in range(K):
     full.run()
