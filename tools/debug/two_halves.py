@@ -1,9 +1,10 @@
 """experiment: two half batches (25 000 reads each, full 64-lane waves) run from two host threads on their own streams, started together
 or a fraction of a launch apart, against one batch of 50 000 -- does work of different phases in flight at the same time relieve the
 fill's write path?  (GA_LANES_SPREAD=0: 391 + 391 waves fit next to each other.)  Prints ms per 50 000 reads of each arrangement.
-Measured (round 3): one batch 32.1 ms; two halves 52.5-52.8 ms whatever the offset -- the two launches did not overlap at all (26 ms
-each, one after the other), so the question is still open; why launches from two non-blocking streams of one process serialise here
-is the first thing to find out."""
+Measured (round 3, after GA_LANES_SPREAD was wired up again -- an earlier run without it had both halves spread over all wave slots
+and told nothing): one batch of 50 000 in 782 full waves 29.4 ms; two halves next to each other 32.1-33.7 ms per 50 000 reads whatever
+the offset (0 / 8 / 15 / 22 ms).  Work of different phases in flight at once did not pay here: each half runs the same instruction
+stream for half the reads per SIMD-slot pair, which costs more than the relieved write path gives back."""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
