@@ -1344,7 +1344,10 @@ template <int N> GAL_FN void lane_finish(const GaLanesLaunch& L, const LaneMem& 
 		// lanes step does not change what any of them computes; the host emulation simply runs each lane on its own.)
 		constexpr int kWin = Lay<N>::T_WINCOLS;
 		constexpr int tWIN = Lay<N>::T_WIN;
-		constexpr int kBurst = kWin - 4;
+#ifndef GAL_BURST_SLACK
+#define GAL_BURST_SLACK 4
+#endif
+		constexpr int kBurst = kWin - GAL_BURST_SLACK;
 		Col q0, q1;
 		q0.vp = q0.vn = 0; q0.before = 0; q1 = q0;
 		bool needSetup = true;
